@@ -1,0 +1,144 @@
+// bwamem_types.h -- plain-data types shared by the host pipeline and the HIP kernels.
+//
+// Layout contracts kept byte-identical with the reference boundary:
+//   MemOpt      = upstream mem_opt_t, 168 bytes, offsets pinned by
+//                 BwaMemAligner.java:46-138
+//   MemPestat   = upstream mem_pestat_t as filled by ...BwaMemIndex.c:21-40
+// Everything else is this implementation's own device-side layout.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+struct MemOpt {
+    int a, b;
+    int o_del, e_del;
+    int o_ins, e_ins;
+    int pen_unpaired;
+    int pen_clip5, pen_clip3;
+    int w;
+    int zdrop;
+    uint64_t max_mem_intv;
+    int T;
+    int flag;
+    int min_seed_len;
+    int min_chain_weight;
+    int max_chain_extend;
+    float split_factor;
+    int split_width;
+    int max_occ;
+    int max_chain_gap;
+    int n_threads;
+    int chunk_size;
+    float mask_level;
+    float drop_ratio;
+    float XA_drop_ratio;
+    float mask_level_redun;
+    float mapQ_coef_len;
+    int mapQ_coef_fac;
+    int max_ins;
+    int max_matesw;
+    int max_XA_hits, max_XA_hits_alt;
+    int8_t mat[25];
+};
+static_assert(sizeof(MemOpt) == 168, "mem_opt_t ABI (BwaMemAligner.java:137)");
+
+struct MemPestat { int low, high; int failed; double avg, std; };
+static_assert(sizeof(MemPestat) == 32, "mem_pestat_t ABI");
+
+enum {
+    MEM_F_PE = 0x2, MEM_F_NOPAIRING = 0x4, MEM_F_ALL = 0x8, MEM_F_NO_MULTI = 0x10,
+    MEM_F_NO_RESCUE = 0x20, MEM_F_PRIMARY5 = 0x800
+};
+
+// ---- FM-index + reference resident in HBM ----
+// occ/bwt blocks: one 64-byte line per 128 BWT symbols = 4 x u64 cumulative counts + 8 x u32 of
+// 16 symbols each, MSB first.  The block array is 64-byte aligned in HBM so
+// one rank query touches exactly one line.
+struct DevIndex {
+    const uint32_t* bwt;
+    const uint64_t* sa;        // sampled every sa_intv ranks; sa[0] = (u64)-1
+    const uint8_t*  pac;       // 2 bit/base, first base in the two MSBs
+    const int64_t*  ann_offset;
+    const int32_t*  ann_len;
+    const int32_t*  ann_is_alt;
+    const int32_t*  ann_name_off;  // n_seqs+1 offsets into names
+    const char*     names;
+    const double*   log_tab;   // glibc log(i) for i in [0, log_tab_n): libm stays on the host
+    uint64_t primary, L2[5], seq_len;
+    int64_t  l_pac;
+    int32_t  n_seqs, sa_intv, log_tab_n, pad_;
+};
+
+struct Intv { uint64_t x0, x1, size, info; };          // info = start<<32 | end
+
+struct Seed { int64_t rbeg; int32_t qbeg, len, score, next; };  // next: chain linked list / scratch
+
+struct Chain {
+    int64_t pos;
+    int32_t n, first, rid;
+    uint32_t w;
+    int32_t kept, is_alt;
+    int32_t seed0;          // index (tile-global) of the chain's first seed in the chain-ordered seed array
+    int32_t last;           // linked-list tail while chaining
+    float frac_rep;
+    int32_t pad_;
+};
+
+struct AlnReg {
+    int64_t rb, re;
+    int32_t qb, qe;
+    int32_t rid;
+    int32_t score, truesc, sub, alt_sc, csub, sub_n, w, seedcov, secondary, secondary_all, seedlen0;
+    int32_t n_comp, is_alt;
+    float frac_rep;
+    int32_t pad_;
+    uint64_t hash;
+};
+
+// per-kernel algorithmic counters; accumulated with one atomic per wave
+struct DevCounters {
+    unsigned long long n_ext, n_lf, n_sa, n_dp_cells, n_ref_bases, n_reads;
+};
+
+// per-tile error / overflow flags set by kernels, read back by the host after each stage
+enum { ERR_INTV_CAP = 1, ERR_OUT_CAP = 2, ERR_CIGAR_CAP = 4, ERR_LONG_READ = 8, ERR_SCRATCH = 16, ERR_BTREE = 32 };
+
+struct TileView {
+    // reads of this tile
+    int32_t n_reads;
+    int32_t max_len;              // longest read in the tile
+    int64_t read_id0;             // index of the tile's first read within the call (hash tie-break)
+    const int64_t* seq_off;       // n_reads+1 offsets into seq
+    uint8_t* seq;                 // base codes 0..4
+    // seeding
+    int32_t intv_cap;             // per-read capacity of intv / scratch vectors
+    Intv* intv;                   // [n_reads][intv_cap]
+    int32_t* n_intv;              // [n_reads]
+    Intv* smem_scratch;           // [n_reads][3][smem_cap]  (mem1, prev, curr)
+    int32_t smem_cap;
+    int32_t* l_rep;               // [n_reads]
+    int32_t* n_seeds;             // [n_reads] -> exclusive scan in seed_off
+    int64_t* seed_off;            // [n_reads+1]
+    int32_t* intv_seed_off;       // [n_reads][intv_cap] offset of each interval's first occurrence within the read
+    // seeds / chains / regions (pools indexed by seed_off)
+    Seed* seeds;                  // occurrence order
+    int32_t* seed_rid;            // rid per occurrence (<0: dropped)
+    Seed* cseeds;                 // chain-ordered
+    Chain* chains;
+    int32_t* n_chains;            // [n_reads]
+    int32_t* bt_nodes;            // B-tree node pool
+    uint64_t* srt;                // per-seed sort keys
+    AlnReg* regs;
+    int32_t* n_regs;              // [n_reads]
+    // output staging
+    int32_t out_cap;              // bytes per read
+    uint8_t* out;                 // [n_reads][out_cap]
+    int32_t* out_len;             // [n_reads]
+    int64_t* out_off;             // [n_reads+1]
+    // per-read scratch for the post stage (global DP etc.)
+    uint8_t* post_scratch;
+    int64_t post_scratch_per_read;
+    // flags + counters
+    int32_t* err;
+    DevCounters* cnt;
+};

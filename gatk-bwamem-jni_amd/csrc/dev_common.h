@@ -1,0 +1,258 @@
+// dev_common.h -- device-side building blocks shared by the kernels: FM-index rank
+// queries on the 64-byte occ/bwt blocks, bidirectional interval extension, sampled-SA
+// lookup, packed-reference access, contig lookup, and the order-exact introsort.
+//
+// Behavioural contract: upstream lh3/bwa bwt.c / bntseq.c / ksort.h as reached from the
+// reference at jnibwa.c:214 (App. B).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "bwamem_types.h"
+
+#define DEV static __device__ inline
+
+// ---------------------------------------------------------------- rank queries (row a2)
+// counts of A,C,G,T among the first n (0..16) symbols of a 16-symbol word (MSB first)
+DEV void cnt_word(uint32_t x, int n, uint32_t& c1, uint32_t& c2, uint32_t& c3)
+{
+    uint32_t m = n >= 16 ? 0x55555555u : (n <= 0 ? 0u : (0x55555555u & ~((1u << (32 - 2 * n)) - 1u)));
+    uint32_t lo = x & m, hi = (x >> 1) & m;
+    c3 += __popc(hi & lo);
+    c2 += __popc(hi & ~lo);
+    c1 += __popc(~hi & lo);
+}
+
+// occ(k, .) for all four symbols: # of c in BWT$[0..k] (k in sentinel-inclusive coordinates)
+DEV void occ4(const DevIndex& ix, uint64_t k, uint64_t cnt[4])
+{
+    if (k == (uint64_t)-1) { cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; return; }
+    k -= (k >= ix.primary);
+    const uint4* p = (const uint4*)(ix.bwt + (k >> 7 << 4));   // one 64-byte line
+    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    int n = (int)(k & 127) + 1;                                // symbols of this block to count
+    uint32_t c1 = 0, c2 = 0, c3 = 0;
+    cnt_word(q2.x, n, c1, c2, c3);       cnt_word(q2.y, n - 16, c1, c2, c3);
+    cnt_word(q2.z, n - 32, c1, c2, c3);  cnt_word(q2.w, n - 48, c1, c2, c3);
+    cnt_word(q3.x, n - 64, c1, c2, c3);  cnt_word(q3.y, n - 80, c1, c2, c3);
+    cnt_word(q3.z, n - 96, c1, c2, c3);  cnt_word(q3.w, n - 112, c1, c2, c3);
+    cnt[0] = ((uint64_t)q0.y << 32 | q0.x) + (uint32_t)(n - (int)(c1 + c2 + c3));
+    cnt[1] = ((uint64_t)q0.w << 32 | q0.z) + c1;
+    cnt[2] = ((uint64_t)q1.y << 32 | q1.x) + c2;
+    cnt[3] = ((uint64_t)q1.w << 32 | q1.z) + c3;
+}
+
+// backward extension of the bi-interval (x0 = interval of P, x1 = interval of revcomp(P)) by
+// every base b: ok[b] is the interval of bP.  Row a3.
+DEV void extend_backward(const DevIndex& ix, const Intv& ik, Intv ok[4])
+{
+    uint64_t tk[4], tl[4];
+    occ4(ix, ik.x0 - 1, tk);
+    occ4(ix, ik.x0 - 1 + ik.size, tl);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ok[i].x0 = ix.L2[i] + 1 + tk[i];
+        ok[i].size = tl[i] - tk[i];
+    }
+    ok[3].x1 = ik.x1 + (ik.x0 <= ix.primary && ik.x0 + ik.size - 1 >= ix.primary);
+    ok[2].x1 = ok[3].x1 + ok[3].size;
+    ok[1].x1 = ok[2].x1 + ok[2].size;
+    ok[0].x1 = ok[1].x1 + ok[1].size;
+}
+
+// forward extension by base b == backward extension of the swapped interval by 3-b;
+// ok[c] (c = 3 - b) is the interval of Pb, as upstream's bwt_extend(..., is_back = 0) returns it.
+DEV void extend_forward(const DevIndex& ix, const Intv& ik, Intv ok[4])
+{
+    Intv sw; sw.x0 = ik.x1; sw.x1 = ik.x0; sw.size = ik.size; sw.info = ik.info;
+    extend_backward(ix, sw, ok);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { uint64_t t = ok[i].x0; ok[i].x0 = ok[i].x1; ok[i].x1 = t; }
+}
+
+DEV void set_intv(const DevIndex& ix, int c, Intv& ik)
+{
+    ik.x0 = ix.L2[c] + 1;
+    ik.size = ix.L2[c + 1] - ix.L2[c];
+    ik.x1 = ix.L2[3 - c] + 1;
+    ik.info = 0;
+}
+
+// text position of rank k: LF-walk to the next sampled rank (row a7); n_lf counts the steps
+DEV uint64_t sa_lookup(const DevIndex& ix, uint64_t k, uint32_t& n_lf)
+{
+    uint64_t sa = 0, mask = (uint64_t)ix.sa_intv - 1;
+    while (k & mask) {
+        ++sa; ++n_lf;
+        if (k == ix.primary) { k = 0; continue; }
+        uint64_t x = k - (k > ix.primary);
+        const uint4* p = (const uint4*)(ix.bwt + (x >> 7 << 4));
+        uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+        uint32_t w[8] = { q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
+        int off = (int)(x & 127);
+        int c = 0;
+        uint32_t c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if ((off >> 4) == i) c = (int)(w[i] >> ((~off & 15) << 1) & 3);
+            cnt_word(w[i], off + 1 - 16 * i, c1, c2, c3);
+        }
+        uint64_t base = c == 0 ? ((uint64_t)q0.y << 32 | q0.x) : c == 1 ? ((uint64_t)q0.w << 32 | q0.z)
+                      : c == 2 ? ((uint64_t)q1.y << 32 | q1.x) : ((uint64_t)q1.w << 32 | q1.z);
+        uint32_t add = c == 0 ? (uint32_t)(off + 1 - (int)(c1 + c2 + c3)) : c == 1 ? c1 : c == 2 ? c2 : c3;
+        k = ix.L2[c] + base + add;
+    }
+    return sa + ix.sa[k / (uint64_t)ix.sa_intv];
+}
+
+// ---------------------------------------------------------------- reference access (U8)
+DEV int pac_base(const uint8_t* pac, int64_t l) { return pac[l >> 2] >> ((~l & 3) << 1) & 3; }
+
+// base at position p of the doubled (forward + reverse-complement) coordinate system
+DEV int ref_base2(const DevIndex& ix, int64_t p)
+{
+    return p < ix.l_pac ? pac_base(ix.pac, p) : 3 - pac_base(ix.pac, (ix.l_pac << 1) - 1 - p);
+}
+
+DEV int64_t bns_depos(const DevIndex& ix, int64_t pos, int& is_rev)
+{
+    return (is_rev = (pos >= ix.l_pac)) ? (ix.l_pac << 1) - 1 - pos : pos;
+}
+
+DEV int bns_pos2rid(const DevIndex& ix, int64_t pos_f)
+{
+    if (pos_f >= ix.l_pac) return -1;
+    int left = 0, mid = 0, right = ix.n_seqs;
+    while (left < right) {
+        mid = (left + right) >> 1;
+        if (pos_f >= ix.ann_offset[mid]) {
+            if (mid == ix.n_seqs - 1) break;
+            if (pos_f < ix.ann_offset[mid + 1]) break;
+            left = mid + 1;
+        } else right = mid;
+    }
+    return mid;
+}
+
+DEV int bns_intv2rid(const DevIndex& ix, int64_t rb, int64_t re)
+{
+    int is_rev;
+    if (rb < ix.l_pac && re > ix.l_pac) return -2;
+    int rid_b = bns_pos2rid(ix, bns_depos(ix, rb, is_rev));
+    int rid_e = rb < re ? bns_pos2rid(ix, bns_depos(ix, re - 1, is_rev)) : rid_b;
+    return rid_b == rid_e ? rid_b : -1;
+}
+
+// clamp [beg,end) to the contig (and strand) that holds mid; upstream bns_fetch_seq's window rule
+DEV void bns_clamp(const DevIndex& ix, int64_t& beg, int64_t mid, int64_t& end, int& rid)
+{
+    int is_rev;
+    if (end < beg) { int64_t t = beg; beg = end; end = t; }
+    rid = bns_pos2rid(ix, bns_depos(ix, mid, is_rev));
+    int64_t far_beg = ix.ann_offset[rid], far_end = far_beg + ix.ann_len[rid];
+    if (is_rev) {
+        int64_t tmp = far_beg;
+        far_beg = (ix.l_pac << 1) - far_end;
+        far_end = (ix.l_pac << 1) - tmp;
+    }
+    beg = beg > far_beg ? beg : far_beg;
+    end = end < far_end ? end : far_end;
+}
+
+DEV uint64_t hash_64(uint64_t key)
+{
+    key += ~(key << 32);
+    key ^= (key >> 22);
+    key += ~(key << 13);
+    key ^= (key >> 8);
+    key += (key << 3);
+    key ^= (key >> 15);
+    key += ~(key << 27);
+    key ^= (key >> 31);
+    return key;
+}
+
+DEV int cal_max_gap(const MemOpt& opt, int qlen)
+{
+    int l_del = (int)((double)(qlen * opt.a - opt.o_del) / opt.e_del + 1.);
+    int l_ins = (int)((double)(qlen * opt.a - opt.o_ins) / opt.e_ins + 1.);
+    int l = l_del > l_ins ? l_del : l_ins;
+    l = l > 1 ? l : 1;
+    return l < opt.w << 1 ? l : opt.w << 1;
+}
+
+// ---------------------------------------------------------------- order-exact sort (U11)
+// The unstable introsort whose tie permutation decides chain / region order:
+// n==2 special case, median-of-three quicksort with explicit stack and depth limit
+// 2*ceil(log2 n) falling back to combsort11, partitions <=16 finished by one insertion pass.
+template <typename T, typename LT>
+DEV void ks_insertsort(T* s, T* t, LT lt)
+{
+    for (T* i = s + 1; i < t; ++i)
+        for (T* j = i; j > s && lt(*j, *(j - 1)); --j) { T tmp = *j; *j = *(j - 1); *(j - 1) = tmp; }
+}
+
+template <typename T, typename LT>
+DEV void ks_combsort(size_t n, T* a, LT lt)
+{
+    const double shrink = 1.2473309501039786540366528676643;
+    int do_swap;
+    size_t gap = n;
+    do {
+        if (gap > 2) { gap = (size_t)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
+        do_swap = 0;
+        for (T* i = a; i < a + n - gap; ++i) {
+            T* j = i + gap;
+            if (lt(*j, *i)) { T tmp = *i; *i = *j; *j = tmp; do_swap = 1; }
+        }
+    } while (do_swap || gap > 2);
+    if (gap != 1) ks_insertsort(a, a + n, lt);
+}
+
+template <typename T, typename LT>
+DEV void ks_introsort(size_t n, T* a, LT lt)
+{
+    struct Frame { T* left; T* right; int depth; };
+    Frame stack[66];
+    Frame* top = stack;
+    if (n < 1) return;
+    if (n == 2) {
+        if (lt(a[1], a[0])) { T tmp = a[0]; a[0] = a[1]; a[1] = tmp; }
+        return;
+    }
+    int d;
+    for (d = 2; 1ul << d < n; ++d);
+    T *s = a, *t = a + (n - 1), *i, *j, *k;
+    d <<= 1;
+    for (;;) {
+        if (s < t) {
+            if (--d == 0) { ks_combsort((size_t)(t - s + 1), s, lt); t = s; continue; }
+            i = s; j = t; k = i + ((j - i) >> 1) + 1;
+            if (lt(*k, *i)) { if (lt(*k, *j)) k = j; }
+            else k = lt(*j, *i) ? i : j;
+            T rp = *k;
+            if (k != t) { T tmp = *k; *k = *t; *t = tmp; }
+            for (;;) {
+                do ++i; while (lt(*i, rp));
+                do --j; while (i <= j && lt(rp, *j));
+                if (j <= i) break;
+                T tmp = *i; *i = *j; *j = tmp;
+            }
+            { T tmp = *i; *i = *t; *t = tmp; }
+            if (i - s > t - i) {
+                if (i - s > 16) { top->left = s; top->right = i - 1; top->depth = d; ++top; }
+                s = t - i > 16 ? i + 1 : t;
+            } else {
+                if (t - i > 16) { top->left = i + 1; top->right = t; top->depth = d; ++top; }
+                t = i - s > 16 ? i - 1 : s;
+            }
+        } else {
+            if (top == stack) { ks_insertsort(a, a + n, lt); return; }
+            --top; s = top->left; t = top->right; d = top->depth;
+        }
+    }
+}
+
+// one atomic per wave for the instrumentation counters
+DEV void count_add(unsigned long long* dst, unsigned long long v)
+{
+    if (v) atomicAdd(dst, v);
+}

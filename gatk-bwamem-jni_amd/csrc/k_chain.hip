@@ -1,0 +1,309 @@
+// k_chain.hip -- seed chaining and chain filtering, one lane per read.
+//
+// Replaces, for the reference call at jnibwa.c:214, upstream bwamem.c mem_chain (the
+// kbtree-keyed greedy chaining + test_and_merge), mem_chain_weight and mem_chain_flt
+// (SURVEY.md rows a8, a9).  The B-tree is kept (t = 5, keys = chain ids ordered by chain.pos)
+// because its insertion rule decides the order of chains with equal keys, and that order
+// feeds the unstable weight sort downstream.  Chains hold their seeds as a
+// linked list threaded through the occurrence array, so no per-chain allocation exists.
+#include "dev_common.h"
+#include "kernels.h"
+
+#define BT_T 5
+#define BT_MAXK (2 * BT_T - 1)
+#define BT_NODE_INTS 22     // is_internal, n, key[9], ptr[10], pad
+
+struct BTree {
+    int32_t* pool; int n_nodes, cap_nodes, root, n_keys;
+    const Chain* cs;         // key -> chain (creation order)
+    bool ovf;
+    __device__ int32_t* node(int i) const { return pool + (size_t)i * BT_NODE_INTS; }
+    __device__ int alloc(int is_internal) {
+        if (n_nodes >= cap_nodes) { ovf = true; return 0; }
+        int32_t* x = node(n_nodes);
+        for (int i = 0; i < BT_NODE_INTS; ++i) x[i] = 0;
+        x[0] = is_internal;
+        return n_nodes++;
+    }
+};
+#define BT_N(x) ((x)[1])
+#define BT_KEY(x) ((x) + 2)
+#define BT_PTR(x) ((x) + 11)
+
+DEV int bt_cmp_pos(int64_t a, int64_t b) { return (b < a) - (a < b); }
+
+// index of the last key < k (or the first key == k); *r = sign(k - key[idx])
+DEV int bt_getp_aux(const BTree& b, const int32_t* x, int64_t kpos, int* r)
+{
+    int tr, *rr = r ? r : &tr, begin = 0, end = BT_N(x);
+    if (BT_N(x) == 0) return -1;
+    while (begin < end) {
+        int mid = (begin + end) >> 1;
+        if (bt_cmp_pos(b.cs[BT_KEY(x)[mid]].pos, kpos) < 0) begin = mid + 1;
+        else end = mid;
+    }
+    if (begin == BT_N(x)) { *rr = 1; return BT_N(x) - 1; }
+    if ((*rr = bt_cmp_pos(kpos, b.cs[BT_KEY(x)[begin]].pos)) < 0) --begin;
+    return begin;
+}
+
+// chain with the largest pos <= kpos along the search path (upstream kb_intervalp's "lower")
+DEV int bt_lower(const BTree& b, int64_t kpos)
+{
+    int lower = -1, r = 0;
+    int xi = b.root;
+    for (;;) {
+        const int32_t* x = b.node(xi);
+        int i = bt_getp_aux(b, x, kpos, &r);
+        if (i >= 0 && r == 0) return BT_KEY(x)[i];
+        if (i >= 0) lower = BT_KEY(x)[i];
+        if (x[0] == 0) return lower;
+        xi = BT_PTR(x)[i + 1];
+    }
+}
+
+DEV void bt_split(BTree& b, int xi, int i, int yi)
+{
+    int zi = b.alloc(b.node(yi)[0]);
+    if (b.ovf) return;
+    int32_t *x = b.node(xi), *y = b.node(yi), *z = b.node(zi);
+    BT_N(z) = BT_T - 1;
+    for (int j = 0; j < BT_T - 1; ++j) BT_KEY(z)[j] = BT_KEY(y)[j + BT_T];
+    if (y[0]) for (int j = 0; j < BT_T; ++j) BT_PTR(z)[j] = BT_PTR(y)[j + BT_T];
+    BT_N(y) = BT_T - 1;
+    for (int j = BT_N(x); j > i; --j) BT_PTR(x)[j + 1] = BT_PTR(x)[j];
+    BT_PTR(x)[i + 1] = zi;
+    for (int j = BT_N(x) - 1; j >= i; --j) BT_KEY(x)[j + 1] = BT_KEY(x)[j];
+    BT_KEY(x)[i] = BT_KEY(y)[BT_T - 1];
+    ++BT_N(x);
+}
+
+DEV void bt_put(BTree& b, int key)
+{
+    int64_t kpos = b.cs[key].pos;
+    ++b.n_keys;
+    int ri = b.root;
+    if (BT_N(b.node(ri)) == BT_MAXK) {
+        int si = b.alloc(1);
+        if (b.ovf) return;
+        b.root = si;
+        BT_PTR(b.node(si))[0] = ri;
+        bt_split(b, si, 0, ri);
+        if (b.ovf) return;
+        ri = si;
+    }
+    int xi = ri;
+    for (;;) {
+        int32_t* x = b.node(xi);
+        if (x[0] == 0) {
+            int i = bt_getp_aux(b, x, kpos, 0);
+            for (int j = BT_N(x) - 1; j > i; --j) BT_KEY(x)[j + 1] = BT_KEY(x)[j];
+            BT_KEY(x)[i + 1] = key;
+            ++BT_N(x);
+            return;
+        }
+        int i = bt_getp_aux(b, x, kpos, 0) + 1;
+        if (BT_N(b.node(BT_PTR(x)[i])) == BT_MAXK) {
+            bt_split(b, xi, i, BT_PTR(x)[i]);
+            if (b.ovf) return;
+            x = b.node(xi);
+            if (bt_cmp_pos(kpos, b.cs[BT_KEY(x)[i]].pos) > 0) ++i;
+        }
+        xi = BT_PTR(x)[i];
+    }
+}
+
+// in-order traversal into out[]; returns the number of keys written
+DEV int bt_traverse(const BTree& b, Chain* out)
+{
+    int st_node[24], st_idx[24], sp = 0, n = 0;
+    st_node[0] = b.root; st_idx[0] = 0; sp = 1;
+    while (sp > 0) {
+        const int32_t* x = b.node(st_node[sp - 1]);
+        int i = st_idx[sp - 1];
+        if (x[0] == 0) {
+            for (int j = 0; j < BT_N(x); ++j) out[n++] = b.cs[BT_KEY(x)[j]];
+            --sp;
+            continue;
+        }
+        if (i > BT_N(x)) { --sp; continue; }
+        if (i > 0) out[n++] = b.cs[BT_KEY(x)[i - 1]];   // key between child i-1 and child i
+        st_idx[sp - 1] = i + 1;
+        if (sp >= 24) return -1;
+        st_node[sp] = BT_PTR(x)[i]; st_idx[sp] = 0; ++sp;
+    }
+    return n;
+}
+
+DEV int test_and_merge(const MemOpt& opt, int64_t l_pac, Chain& c, Seed* seeds, int si, int seed_rid)
+{
+    const Seed p = seeds[si];
+    const Seed first = seeds[c.seed0], last = seeds[c.last];
+    int64_t qend = last.qbeg + last.len, rend = last.rbeg + last.len;
+    if (seed_rid != c.rid) return 0;
+    if (p.qbeg >= first.qbeg && p.qbeg + p.len <= qend && p.rbeg >= first.rbeg && p.rbeg + p.len <= rend)
+        return 1;                                    // contained: absorbed, not stored
+    if ((last.rbeg < l_pac || first.rbeg < l_pac) && p.rbeg >= l_pac) return 0;
+    int64_t x = p.qbeg - last.qbeg, y = p.rbeg - last.rbeg;
+    if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - last.len < opt.max_chain_gap && y - last.len < opt.max_chain_gap) {
+        seeds[c.last].next = si;
+        c.last = si;
+        ++c.n;
+        return 1;
+    }
+    return 0;
+}
+
+DEV int chain_weight(const Chain& c, const Seed* seeds)
+{
+    int64_t end = 0;
+    int w = 0, tmp, j, si;
+    for (j = 0, si = c.seed0; j < c.n; ++j, si = seeds[si].next) {
+        const Seed s = seeds[si];
+        if (s.qbeg >= end) w += s.len;
+        else if (s.qbeg + s.len > end) w += (int)(s.qbeg + s.len - end);
+        end = end > s.qbeg + s.len ? end : s.qbeg + s.len;
+    }
+    tmp = w; w = 0;
+    for (j = 0, end = 0, si = c.seed0; j < c.n; ++j, si = seeds[si].next) {
+        const Seed s = seeds[si];
+        if (s.rbeg >= end) w += s.len;
+        else if (s.rbeg + s.len > end) w += (int)(s.rbeg + s.len - end);
+        end = end > s.rbeg + s.len ? end : s.rbeg + s.len;
+    }
+    w = w < tmp ? w : tmp;
+    return w < 1 << 30 ? w : (1 << 30) - 1;
+}
+
+struct ChainWLt { __device__ bool operator()(const Chain& a, const Chain& b) const { return a.w > b.w; } };
+
+__global__ void k_chain(DevIndex ix, MemOpt opt, TileView tv, Chain* chain_store)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= tv.n_reads) return;
+    int64_t s0 = tv.seed_off[r], s1 = tv.seed_off[r + 1];
+    int len = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
+    Seed* seeds = tv.seeds;              // tile-global indices
+    Chain* cs = chain_store + s0;        // creation order
+    Chain* a = tv.chains + s0;           // B-tree order, then filtered
+    int n_cs = 0;
+    tv.n_chains[r] = 0;
+    if (s1 == s0) return;
+
+    BTree bt;
+    int64_t node0 = s0 / 4 + 3 * (int64_t)r;
+    bt.pool = tv.bt_nodes + node0 * BT_NODE_INTS;
+    bt.cap_nodes = (int)((s1 / 4 + 3 * (int64_t)(r + 1)) - node0);
+    bt.n_nodes = 0; bt.n_keys = 0; bt.cs = cs; bt.ovf = false;
+    bt.root = bt.alloc(0);
+
+    for (int64_t g = s0; g < s1; ++g) {
+        int rid = tv.seed_rid[g];
+        if (rid < 0) continue;
+        int to_add = 0;
+        if (bt.n_keys) {
+            int lower = bt_lower(bt, seeds[g].rbeg);
+            if (lower < 0 || !test_and_merge(opt, ix.l_pac, cs[lower], seeds, (int)g, rid)) to_add = 1;
+        } else to_add = 1;
+        if (to_add) {
+            Chain c;
+            c.pos = seeds[g].rbeg; c.n = 1; c.first = -1; c.rid = rid; c.w = 0; c.kept = 0;
+            c.is_alt = ix.ann_is_alt[rid] != 0;
+            c.seed0 = (int)g; c.last = (int)g; c.frac_rep = 0.f; c.pad_ = 0;
+            cs[n_cs] = c;
+            bt_put(bt, n_cs);
+            ++n_cs;
+            if (bt.ovf) { atomicOr(tv.err, ERR_BTREE); return; }
+        }
+    }
+    int n_chn = bt_traverse(bt, a);
+    if (n_chn < 0) { atomicOr(tv.err, ERR_BTREE); return; }
+    float frac_rep = (float)tv.l_rep[r] / len;
+    for (int i = 0; i < n_chn; ++i) a[i].frac_rep = frac_rep;
+
+    // ---- mem_chain_flt (row a9)
+    if (n_chn > 0) {
+        int i, k;
+        for (i = k = 0; i < n_chn; ++i) {
+            Chain c = a[i];
+            c.first = -1; c.kept = 0;
+            c.w = (uint32_t)chain_weight(c, seeds);
+            if ((int)c.w >= opt.min_chain_weight) a[k++] = c;
+        }
+        n_chn = k;
+    }
+    if (n_chn > 0) {
+        int i, k, n_kept = 0;
+        int32_t* kept_idx = (int32_t*)(tv.srt + s0);   // scratch: >= n_chn ints
+        ks_introsort((size_t)n_chn, a, ChainWLt());
+        a[0].kept = 3;
+        kept_idx[n_kept++] = 0;
+        for (i = 1; i < n_chn; ++i) {
+            int large_ovlp = 0;
+            int bi = seeds[a[i].seed0].qbeg, ei = seeds[a[i].last].qbeg + seeds[a[i].last].len;
+            for (k = 0; k < n_kept; ++k) {
+                int j = kept_idx[k];
+                int bj = seeds[a[j].seed0].qbeg, ej = seeds[a[j].last].qbeg + seeds[a[j].last].len;
+                int b_max = bj > bi ? bj : bi;
+                int e_min = ej < ei ? ej : ei;
+                if (e_min > b_max && (!a[j].is_alt || a[i].is_alt)) {
+                    int li = ei - bi, lj = ej - bj;
+                    int min_l = li < lj ? li : lj;
+                    if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level && min_l < opt.max_chain_gap) {
+                        large_ovlp = 1;
+                        if (a[j].first < 0) a[j].first = i;
+                        if ((float)(int)a[i].w < (float)(int)a[j].w * opt.drop_ratio && (int)a[j].w - (int)a[i].w >= opt.min_seed_len << 1)
+                            break;
+                    }
+                }
+            }
+            if (k == n_kept) {
+                kept_idx[n_kept++] = i;
+                a[i].kept = large_ovlp ? 2 : 3;
+            }
+        }
+        for (i = 0; i < n_kept; ++i) {
+            int f = a[kept_idx[i]].first;
+            if (f >= 0) a[f].kept = 1;
+        }
+        for (i = k = 0; i < n_chn; ++i) {
+            if (a[i].kept == 0 || a[i].kept == 3) continue;
+            if (++k >= opt.max_chain_extend) break;
+        }
+        for (; i < n_chn; ++i)
+            if (a[i].kept < 3) a[i].kept = 0;
+        for (i = k = 0; i < n_chn; ++i)
+            if (a[i].kept != 0) a[k++] = a[i];
+        n_chn = k;
+    }
+
+    // ---- mem_flt_chained_seeds (row a10) is active only for long reads (5.5 ln L <= 0.05 L)
+    {
+        double min_l = opt.min_chain_weight ? 1.1f * opt.min_chain_weight
+                     : 5.5f * (len < ix.log_tab_n ? ix.log_tab[len] : 1e30);
+        if (!(min_l > 0.05f * len) && n_chn > 0) atomicOr(tv.err, ERR_LONG_READ);
+    }
+
+    // ---- lay the kept chains' seeds out contiguously, chain by chain
+    {
+        Seed* out = tv.cseeds;
+        int64_t o = s0;
+        for (int i = 0; i < n_chn; ++i) {
+            int si = a[i].seed0;
+            a[i].seed0 = (int32_t)(o - s0);
+            for (int j = 0; j < a[i].n; ++j) {
+                Seed s = seeds[si];
+                si = s.next;
+                s.next = -1;
+                out[o++] = s;
+            }
+        }
+    }
+    tv.n_chains[r] = n_chn;
+}
+
+void launch_chain(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, Chain* chain_store)
+{
+    if (tv.n_reads <= 0) return;
+    hipLaunchKernelGGL(k_chain, dim3((tv.n_reads + 63) / 64), dim3(64), 0, st, ix, opt, tv, chain_store);
+}

@@ -1,0 +1,327 @@
+// k_extend.hip -- chain -> alignment regions by banded affine-gap extension, one wavefront
+// per read.
+//
+// Replaces, for the reference call at jnibwa.c:214, upstream bwamem.c mem_chain2aln and
+// ksw.c ksw_extend2.  The per-read control flow (which seed to
+// extend, band retries, local vs. to-end choice) is sequential and wave-uniform; the DP row
+// is the parallel dimension: lane l owns query column c + l of the current 64-column chunk.
+// Within a row M(i,j) and E(i,j) depend only on row i-1, and F(i,j) is a max-plus prefix of
+// M(i,.), so it is computed with a wavefront shuffle scan; H/E rows live in LDS with the
+// in-place (eh[]) update order kept, because stale cells outside the live window are
+// observable through the window-growth rule.  Integer scoring throughout: no MFMA.
+#include "dev_common.h"
+#include "wave_ops.h"
+#include "kernels.h"
+
+struct ExtRes { int score, qle, tle, gtle, gscore, max_off; };
+
+struct ExtLds { int32_t* eh_h; int32_t* eh_e; int32_t* tmpM; const uint8_t* query; };
+
+// ksw_extend2 with the query read as query[q0 + qstep*j] and the target as the doubled-strand
+// reference base at t0 + tstep*i.
+static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, const ExtLds& L, int lane,
+                                     int qlen, int q0, int qstep, int tlen, int64_t t0, int tstep,
+                                     int w, int end_bonus, int zdrop, int h0, unsigned long long& n_cells)
+{
+    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    int i, beg, end, max, max_i, max_j, max_ins, max_del, max_ie, gscore, max_off;
+    if (h0 < 0) h0 = 0;
+    // first row: decay from h0 by insertion costs
+    for (int j = lane; j <= qlen; j += WAVE) {
+        int v = 0;
+        if (j == 0) v = h0;
+        else if (h0 > oe_ins) {
+            int vj = h0 - oe_ins - (j - 1) * e_ins;       // value if the decay chain reaches column j
+            if (j == 1 || vj + e_ins > e_ins) v = vj;     // previous cell > e_ins
+        }
+        L.eh_h[j] = v; L.eh_e[j] = 0;
+    }
+    {   // clip the band by the longest affordable gap
+        int mx = 0;
+        for (int k = 0; k < 25; ++k) mx = mx > opt.mat[k] ? mx : opt.mat[k];
+        max_ins = (int)((double)(qlen * mx + end_bonus - o_ins) / e_ins + 1.);
+        max_ins = max_ins > 1 ? max_ins : 1;
+        w = w < max_ins ? w : max_ins;
+        max_del = (int)((double)(qlen * mx + end_bonus - o_del) / e_del + 1.);
+        max_del = max_del > 1 ? max_del : 1;
+        w = w < max_del ? w : max_del;
+    }
+    max = h0; max_i = max_j = -1; max_ie = -1; gscore = -1; max_off = 0;
+    beg = 0; end = qlen;
+    int tch = 4;
+    __syncthreads();
+    for (i = 0; i < tlen; ++i) {
+        if ((i & 63) == 0) {                               // 64 target bases, one per lane
+            int ii = i + lane;
+            tch = ii < tlen ? ref_base2(ix, t0 + (int64_t)tstep * ii) : 4;
+        }
+        const int tb = wave_bcast(tch, i & 63);
+        const int ms0 = opt.mat[tb * 5], ms1 = opt.mat[tb * 5 + 1], ms2 = opt.mat[tb * 5 + 2], ms3 = opt.mat[tb * 5 + 3], ms4 = opt.mat[tb * 5 + 4];
+        int m = 0, mj = -1, h1, h1i, hlast = 0;
+        if (beg < i - w) beg = i - w;
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        if (beg == 0) { h1i = h0 - (o_del + e_del * (i + 1)); if (h1i < 0) h1i = 0; }
+        else h1i = 0;
+        h1 = h1i;
+        // phase A: M(i,j) from the previous row, before any cell of eh_h is overwritten
+        for (int c = beg; c < end; c += WAVE) {
+            int j = c + lane;
+            if (j < end) {
+                int Mp = L.eh_h[j];
+                int qc = L.query[q0 + qstep * j];
+                int sc = qc == 0 ? ms0 : qc == 1 ? ms1 : qc == 2 ? ms2 : qc == 3 ? ms3 : ms4;
+                L.tmpM[j] = Mp ? Mp + sc : 0;
+            }
+        }
+        __syncthreads();
+        // phase B: F by prefix scan, H, E, row maximum; writes eh_h[j+1], eh_e[j]
+        int fcarry = 0;
+        for (int c = beg; c < end; c += WAVE) {
+            int j = c + lane;
+            bool act = j < end;
+            int M = act ? L.tmpM[j] : 0;
+            int e = act ? L.eh_e[j] : 0;
+            int t = M - oe_ins; t = t > 0 ? t : 0;
+            int U = act ? t + j * e_ins : NEG_INF_I32;
+            int P = wave_prefix_max(U, lane);
+            int Pex = __shfl_up(P, 1);
+            int f = fcarry - (j - c) * e_ins;
+            if (lane > 0) { int g = Pex - (j - 1) * e_ins; f = f > g ? f : g; }
+            int h = M > e ? M : e;
+            h = h > f ? h : f;
+            if (!act) h = -1;
+            int mc = wave_max(h);
+            unsigned long long bal = wave_ballot(act && h == mc);
+            int mjc = c + 63 - __clzll(bal);
+            if (mc >= m) { m = mc; mj = mjc; }
+            int last = (end - 1 - c) < 63 ? (end - 1 - c) : 63;
+            hlast = wave_bcast(h, last);
+            int Plast = wave_bcast(P, 63);
+            {   // F at column c+64 for the next chunk
+                int f1 = fcarry - WAVE * e_ins, f2 = Plast - (c + 63) * e_ins;
+                fcarry = f1 > f2 ? f1 : f2;
+            }
+            if (act) {
+                int t2 = M - oe_del; t2 = t2 > 0 ? t2 : 0;
+                int en = e - e_del; en = en > t2 ? en : t2;
+                L.eh_e[j] = en;
+                L.eh_h[j + 1] = h;
+            }
+        }
+        if (end > beg) {                                   // eh[beg].h = first-column value, eh[end].h = H(i,end-1)
+            n_cells += (unsigned long long)(end - beg);
+            h1 = hlast;
+            if (lane == 0) L.eh_h[beg] = h1i;
+        } else if (lane == 0) L.eh_h[end] = h1i;
+        if (lane == 0) L.eh_e[end] = 0;
+        {
+            int jafter = end > beg ? end : beg;
+            if (jafter == qlen) {
+                max_ie = gscore > h1 ? max_ie : i;
+                gscore = gscore > h1 ? gscore : h1;
+            }
+        }
+        if (m == 0) break;
+        if (m > max) {
+            max = m; max_i = i; max_j = mj;
+            int d = mj - i; d = d < 0 ? -d : d;
+            max_off = max_off > d ? max_off : d;
+        } else if (zdrop > 0) {
+            if (i - max_i > mj - max_j) {
+                if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
+            } else {
+                if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
+            }
+        }
+        __syncthreads();
+        // shrink the window to the non-zero span of the row just written
+        {
+            int nb = end;
+            for (int c = beg; c < end; c += WAVE) {
+                int j = c + lane;
+                int nz = j < end && (L.eh_h[j] != 0 || L.eh_e[j] != 0);
+                unsigned long long bal = wave_ballot(nz);
+                if (bal) { nb = c + __ffsll((long long)bal) - 1; break; }
+            }
+            beg = nb;
+            int jl = beg - 1;
+            for (int hi = end; hi >= beg; hi -= WAVE) {
+                int p = hi - lane;
+                int nz = p >= beg && (L.eh_h[p] != 0 || L.eh_e[p] != 0);
+                unsigned long long bal = wave_ballot(nz);
+                if (bal) { jl = hi - (__ffsll((long long)bal) - 1); break; }
+            }
+            end = jl + 2 < qlen ? jl + 2 : qlen;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    ExtRes r;
+    r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+    return r;
+}
+
+struct U64Lt { __device__ bool operator()(uint64_t a, uint64_t b) const { return a < b; } };
+
+#define MAX_BAND_TRY 2
+
+__global__ void __launch_bounds__(64) k_extend(DevIndex ix, MemOpt opt, TileView tv)
+{
+    HIP_DYNAMIC_SHARED(int32_t, smem)
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const int64_t s0 = tv.seed_off[r];
+    const int l_query = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
+    const int cap = tv.max_len + 2;
+    ExtLds L;
+    L.eh_h = smem; L.eh_e = smem + cap; L.tmpM = smem + 2 * cap;
+    uint8_t* sq = (uint8_t*)(smem + 3 * cap);
+    L.query = sq;
+    for (int j = lane; j < l_query; j += WAVE) sq[j] = tv.seq[tv.seq_off[r] + j];
+    __syncthreads();
+
+    const int n_chn = tv.n_chains[r];
+    const Chain* chains = tv.chains + s0;
+    AlnReg* regs = tv.regs + s0;
+    uint64_t* srt = tv.srt + s0;
+    const int64_t l_pac = ix.l_pac;
+    int n_regs = 0;
+    unsigned long long n_cells = 0;
+
+    for (int ci = 0; ci < n_chn; ++ci) {
+        const Chain c = chains[ci];
+        const Seed* seeds = tv.cseeds + s0 + c.seed0;
+        if (c.n == 0) continue;
+        int64_t rmax0 = l_pac << 1, rmax1 = 0;
+        for (int i = 0; i < c.n; ++i) {
+            const Seed t = seeds[i];
+            int64_t b = t.rbeg - (t.qbeg + cal_max_gap(opt, t.qbeg));
+            int64_t e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + cal_max_gap(opt, l_query - t.qbeg - t.len));
+            rmax0 = rmax0 < b ? rmax0 : b;
+            rmax1 = rmax1 > e ? rmax1 : e;
+        }
+        rmax0 = rmax0 > 0 ? rmax0 : 0;
+        rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+        if (rmax0 < l_pac && l_pac < rmax1) {
+            if (seeds[0].rbeg < l_pac) rmax1 = l_pac;
+            else rmax0 = l_pac;
+        }
+        { int rid; bns_clamp(ix, rmax0, seeds[0].rbeg, rmax1, rid); }
+
+        if (lane == 0) {
+            for (int i = 0; i < c.n; ++i) srt[i] = (uint64_t)(uint32_t)seeds[i].score << 32 | (uint32_t)i;
+            ks_introsort((size_t)c.n, srt, U64Lt());
+        }
+        __syncthreads();
+
+        for (int k = c.n - 1; k >= 0; --k) {
+            const Seed s = seeds[(uint32_t)srt[k]];
+            int i;
+            for (i = 0; i < n_regs; ++i) {            // already covered by an earlier region?
+                const AlnReg p = regs[i];
+                int64_t rd; int qd, w, max_gap;
+                if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) continue;
+                if (s.len - p.seedlen0 > .1 * l_query) continue;
+                qd = s.qbeg - p.qb; rd = s.rbeg - p.rb;
+                max_gap = cal_max_gap(opt, qd < rd ? qd : (int)rd);
+                w = max_gap < p.w ? max_gap : p.w;
+                if (qd - rd < w && rd - qd < w) break;
+                qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
+                max_gap = cal_max_gap(opt, qd < rd ? qd : (int)rd);
+                w = max_gap < p.w ? max_gap : p.w;
+                if (qd - rd < w && rd - qd < w) break;
+            }
+            if (i < n_regs) {
+                for (i = k + 1; i < c.n; ++i) {       // an overlapping off-diagonal seed forces extension
+                    if (srt[i] == 0) continue;
+                    const Seed t = seeds[(uint32_t)srt[i]];
+                    if (t.len < s.len * .95) continue;
+                    if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) break;
+                    if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) break;
+                }
+                if (i == c.n) {
+                    __syncthreads();
+                    if (lane == 0) srt[k] = 0;
+                    __syncthreads();
+                    continue;
+                }
+            }
+
+            AlnReg a;
+            a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.alt_sc = a.csub = a.sub_n = 0; a.seedcov = 0;
+            a.secondary = a.secondary_all = 0; a.seedlen0 = 0; a.n_comp = 0; a.is_alt = 0; a.frac_rep = 0.f; a.pad_ = 0; a.hash = 0;
+            int aw0 = opt.w, aw1 = opt.w;
+            a.w = opt.w;
+            a.score = a.truesc = -1;
+            a.rid = c.rid;
+
+            if (s.qbeg) {                              // left extension, both sequences reversed
+                int64_t tmp = s.rbeg - rmax0;
+                ExtRes e; e.score = e.qle = e.tle = e.gtle = e.gscore = e.max_off = 0;
+                for (i = 0; i < MAX_BAND_TRY; ++i) {
+                    int prev = a.score;
+                    aw0 = opt.w << i;
+                    e = extend_wave(ix, opt, L, lane, s.qbeg, s.qbeg - 1, -1, (int)tmp, s.rbeg - 1, -1,
+                                    aw0, opt.pen_clip5, opt.zdrop, s.len * opt.a, n_cells);
+                    a.score = e.score;
+                    if (a.score == prev || e.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
+                }
+                if (e.gscore <= 0 || e.gscore <= a.score - opt.pen_clip5) {
+                    a.qb = s.qbeg - e.qle; a.rb = s.rbeg - e.tle;
+                    a.truesc = a.score;
+                } else {
+                    a.qb = 0; a.rb = s.rbeg - e.gtle;
+                    a.truesc = e.gscore;
+                }
+            } else { a.score = a.truesc = s.len * opt.a; a.qb = 0; a.rb = s.rbeg; }
+
+            if (s.qbeg + s.len != l_query) {           // right extension
+                int qe = s.qbeg + s.len, sc0 = a.score;
+                int64_t re = s.rbeg + s.len - rmax0;
+                ExtRes e; e.score = e.qle = e.tle = e.gtle = e.gscore = e.max_off = 0;
+                for (i = 0; i < MAX_BAND_TRY; ++i) {
+                    int prev = a.score;
+                    aw1 = opt.w << i;
+                    e = extend_wave(ix, opt, L, lane, l_query - qe, qe, 1, (int)(rmax1 - rmax0 - re), rmax0 + re, 1,
+                                    aw1, opt.pen_clip3, opt.zdrop, sc0, n_cells);
+                    a.score = e.score;
+                    if (a.score == prev || e.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
+                }
+                if (e.gscore <= 0 || e.gscore <= a.score - opt.pen_clip3) {
+                    a.qe = qe + e.qle; a.re = rmax0 + re + e.tle;
+                    a.truesc += a.score - sc0;
+                } else {
+                    a.qe = l_query; a.re = rmax0 + re + e.gtle;
+                    a.truesc += e.gscore - sc0;
+                }
+            } else { a.qe = l_query; a.re = s.rbeg + s.len; }
+
+            a.seedcov = 0;
+            for (i = 0; i < c.n; ++i) {
+                const Seed t = seeds[i];
+                if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re)
+                    a.seedcov += t.len;
+            }
+            a.w = aw0 > aw1 ? aw0 : aw1;
+            a.seedlen0 = s.len;
+            a.frac_rep = c.frac_rep;
+            __syncthreads();
+            if (lane == 0) regs[n_regs] = a;
+            ++n_regs;
+            __syncthreads();
+        }
+    }
+    if (lane == 0) {
+        tv.n_regs[r] = n_regs;
+        count_add(&tv.cnt->n_dp_cells, n_cells);
+    }
+}
+
+void launch_extend(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv)
+{
+    if (tv.n_reads <= 0) return;
+    size_t cap = (size_t)tv.max_len + 2;
+    size_t shmem = 3 * cap * sizeof(int32_t) + ((cap + 15) & ~(size_t)15);
+    hipLaunchKernelGGL(k_extend, dim3(tv.n_reads), dim3(64), shmem, st, ix, opt, tv);
+}

@@ -1,0 +1,276 @@
+// k_seed.hip -- seeding kernels: base encoding, three-pass SMEM collection over the
+// HBM-resident occ table, seed-occurrence counting + scan, and sampled-SA lookup.
+//
+// Replaces, for the reference call at jnibwa.c:214, upstream bwamem.c mem_collect_intv and
+// bwt.c bwt_smem1 / bwt_seed_strategy1 / bwt_extend / bwt_2occ4 / bwt_sa (SURVEY.md rows
+// a2-a7).  One lane walks one read: every interval extension is two dependent random
+// 64-byte gathers, so throughput comes from the number of independent reads in flight per
+// CU, not from parallelism inside a read.
+#include "dev_common.h"
+#include "kernels.h"
+
+struct IntvVec {
+    Intv* a; int n; int cap;
+    __device__ bool push(const Intv& v) { if (n >= cap) return false; a[n++] = v; return true; }
+};
+
+DEV void vec_reverse(IntvVec& v)
+{
+    for (int i = 0; i < v.n >> 1; ++i) { Intv t = v.a[i]; v.a[i] = v.a[v.n - 1 - i]; v.a[v.n - 1 - i] = t; }
+}
+
+// all SMEMs through position x with interval size >= min_intv; returns the next x.
+// Forward-extend recording each size change, then backward-extend every candidate in lock-step,
+// longest first (App. B "SMEM(x, min_intv)").
+DEV int smem1(const DevIndex& ix, int len, const uint8_t* q, int x, int min_intv,
+              IntvVec& mem, IntvVec& v0, IntvVec& v1, uint32_t& n_ext, bool& ovf)
+{
+    Intv ik, ok[4];
+    IntvVec *prev = &v0, *curr = &v1, *swap;
+    int i, j, c;
+    mem.n = 0;
+    if (q[x] > 3) return x + 1;
+    if (min_intv < 1) min_intv = 1;
+    set_intv(ix, q[x], ik);
+    ik.info = (uint64_t)(x + 1);
+    for (i = x + 1, curr->n = 0; i < len; ++i) {
+        if (q[i] < 4) {
+            c = 3 - q[i];
+            extend_forward(ix, ik, ok); ++n_ext;
+            if (ok[c].size != ik.size) {
+                if (!curr->push(ik)) { ovf = true; return len; }
+                if (ok[c].size < (uint64_t)min_intv) break;
+            }
+            ik = ok[c]; ik.info = (uint64_t)(i + 1);
+        } else {
+            if (!curr->push(ik)) { ovf = true; return len; }
+            break;
+        }
+    }
+    if (i == len) { if (!curr->push(ik)) { ovf = true; return len; } }
+    vec_reverse(*curr);
+    int ret = (int)curr->a[0].info;
+    swap = curr; curr = prev; prev = swap;
+    for (i = x - 1; i >= -1; --i) {
+        c = i < 0 ? -1 : q[i] < 4 ? q[i] : -1;
+        for (j = 0, curr->n = 0; j < prev->n; ++j) {
+            Intv p = prev->a[j];
+            if (c >= 0) { extend_backward(ix, p, ok); ++n_ext; }
+            if (c < 0 || ok[c].size < (uint64_t)min_intv) {
+                if (curr->n == 0) {
+                    if (mem.n == 0 || (uint64_t)(i + 1) < mem.a[mem.n - 1].info >> 32) {
+                        ik = p; ik.info |= (uint64_t)(i + 1) << 32;
+                        if (!mem.push(ik)) { ovf = true; return len; }
+                    }
+                }
+            } else if (curr->n == 0 || ok[c].size != curr->a[curr->n - 1].size) {
+                ok[c].info = p.info;
+                if (!curr->push(ok[c])) { ovf = true; return len; }
+            }
+        }
+        if (curr->n == 0) break;
+        swap = curr; curr = prev; prev = swap;
+    }
+    vec_reverse(mem);
+    return ret;
+}
+
+// pass 3: greedy forward seed (row a5)
+DEV int seed_strategy1(const DevIndex& ix, int len, const uint8_t* q, int x, int min_len, int max_intv, Intv& mem, uint32_t& n_ext)
+{
+    Intv ik, ok[4];
+    mem.x0 = mem.x1 = mem.size = mem.info = 0;
+    if (q[x] > 3) return x + 1;
+    set_intv(ix, q[x], ik);
+    for (int i = x + 1; i < len; ++i) {
+        if (q[i] < 4) {
+            int c = 3 - q[i];
+            extend_forward(ix, ik, ok); ++n_ext;
+            if (ok[c].size < (uint64_t)(int64_t)max_intv && i - x >= min_len) {
+                mem = ok[c];
+                mem.info = (uint64_t)x << 32 | (uint32_t)(i + 1);
+                return i + 1;
+            }
+            ik = ok[c];
+        } else return i + 1;
+    }
+    return len;
+}
+
+// ASCII -> 0..4 in place (upstream nst_nt4_table; bytes < 4 are kept as they are)
+__global__ void k_encode(uint8_t* seq, int64_t n_bytes)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n_bytes; i += stride) {
+        uint8_t c = seq[i];
+        if (c >= 4) {
+            uint8_t u = c & 0xdf;   // fold case
+            c = u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : 4;
+            seq[i] = c;
+        }
+    }
+}
+
+struct IntvInfoLt { __device__ bool operator()(const Intv& a, const Intv& b) const { return a.info < b.info; } };
+
+// mem_collect_intv (row a6) + the per-read bookkeeping mem_chain does before looking up the SA:
+// l_rep (repetitive fraction numerator) and the number of occurrences each interval contributes.
+__global__ void k_seed(DevIndex ix, MemOpt opt, TileView tv)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_ext = 0;
+    if (r < tv.n_reads) {
+        const uint8_t* q = tv.seq + tv.seq_off[r];
+        int len = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
+        IntvVec mem  = { tv.intv + (size_t)r * tv.intv_cap, 0, tv.intv_cap };
+        Intv* sc = tv.smem_scratch + (size_t)r * 3 * tv.smem_cap;
+        IntvVec mem1 = { sc, 0, tv.smem_cap };
+        IntvVec v0   = { sc + tv.smem_cap, 0, tv.smem_cap };
+        IntvVec v1   = { sc + 2 * (size_t)tv.smem_cap, 0, tv.smem_cap };
+        bool ovf = false;
+        int n_seeds = 0, l_rep = 0;
+        if (len >= opt.min_seed_len) {
+            int x = 0;
+            int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
+            while (x < len && !ovf) {                       // pass 1: all SMEMs
+                if (q[x] < 4) {
+                    x = smem1(ix, len, q, x, 1, mem1, v0, v1, n_ext, ovf);
+                    for (int i = 0; i < mem1.n && !ovf; ++i) {
+                        Intv p = mem1.a[i];
+                        int slen = (int)((uint32_t)p.info - (uint32_t)(p.info >> 32));
+                        if (slen >= opt.min_seed_len) { if (!mem.push(p)) ovf = true; }
+                    }
+                } else ++x;
+            }
+            int old_n = mem.n;
+            for (int k = 0; k < old_n && !ovf; ++k) {       // pass 2: re-seed long, rare SMEMs
+                Intv p = mem.a[k];
+                int start = (int)(p.info >> 32), end = (int)(int32_t)p.info;
+                if (end - start < split_len || p.size > (uint64_t)(int64_t)opt.split_width) continue;
+                smem1(ix, len, q, (start + end) >> 1, (int)(p.size + 1), mem1, v0, v1, n_ext, ovf);
+                for (int i = 0; i < mem1.n && !ovf; ++i) {
+                    Intv m = mem1.a[i];
+                    if ((int)((uint32_t)m.info - (uint32_t)(m.info >> 32)) >= opt.min_seed_len) { if (!mem.push(m)) ovf = true; }
+                }
+            }
+            if (opt.max_mem_intv > 0) {                     // pass 3: greedy forward seeds
+                x = 0;
+                while (x < len && !ovf) {
+                    if (q[x] < 4) {
+                        Intv m;
+                        x = seed_strategy1(ix, len, q, x, opt.min_seed_len, (int)opt.max_mem_intv, m, n_ext);
+                        if (m.size > 0) { if (!mem.push(m)) ovf = true; }
+                    } else ++x;
+                }
+            }
+            if (!ovf) {
+                ks_introsort((size_t)mem.n, mem.a, IntvInfoLt());
+                int b = 0, e = 0;
+                int32_t* iso = tv.intv_seed_off + (size_t)r * tv.intv_cap;
+                for (int i = 0; i < mem.n; ++i) {
+                    Intv p = mem.a[i];
+                    int sb = (int)(p.info >> 32), se = (int)(uint32_t)p.info;
+                    iso[i] = n_seeds;
+                    {
+                        int64_t step = p.size > (uint64_t)(int64_t)opt.max_occ ? (int64_t)(p.size / (uint64_t)opt.max_occ) : 1;
+                        int64_t c = ((int64_t)p.size + step - 1) / step;
+                        n_seeds += (int)(c < opt.max_occ ? c : opt.max_occ);
+                    }
+                    if (p.size <= (uint64_t)(int64_t)opt.max_occ) continue;
+                    if (sb > e) { l_rep += e - b; b = sb; e = se; }
+                    else e = e > se ? e : se;
+                }
+                l_rep += e - b;
+            }
+        }
+        if (ovf) { atomicOr(tv.err, ERR_INTV_CAP); mem.n = 0; n_seeds = 0; l_rep = 0; }
+        tv.n_intv[r] = mem.n;
+        tv.n_seeds[r] = n_seeds;
+        tv.l_rep[r] = l_rep;
+    }
+    // one counter atomic per wave
+    unsigned long long tot = n_ext;
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o);
+    if ((threadIdx.x & 63) == 0) { count_add(&tv.cnt->n_ext, tot); }
+}
+
+// exclusive scan int32 -> int64 (single workgroup; n is a tile's read count, so this is tiny)
+__global__ void k_scan(const int32_t* in, int64_t* out, int n)
+{
+    __shared__ int64_t part[1024];
+    __shared__ int64_t carry;
+    int t = threadIdx.x, nt = blockDim.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += nt) {
+        int i = base + t;
+        int64_t v = i < n ? in[i] : 0;
+        part[t] = v;
+        __syncthreads();
+        for (int o = 1; o < nt; o <<= 1) {
+            int64_t add = t >= o ? part[t - o] : 0;
+            __syncthreads();
+            part[t] += add;
+            __syncthreads();
+        }
+        if (i < n) out[i] = carry + part[t] - v;
+        __syncthreads();
+        if (t == nt - 1) carry += part[t];
+        __syncthreads();
+    }
+    if (t == 0) out[n] = carry;
+}
+
+// one lane per seed occurrence: rank -> text position by LF-walk + sample (row a7), then the
+// contig test of mem_chain (bns_intv2rid; occurrences bridging contigs or strands are dropped)
+__global__ void k_sa(DevIndex ix, MemOpt opt, TileView tv, int64_t n_occ)
+{
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_lf = 0, n_sa = 0;
+    if (g < n_occ) {
+        int lo = 0, hi = tv.n_reads;                    // read r with seed_off[r] <= g < seed_off[r+1]
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (tv.seed_off[mid] <= g) lo = mid; else hi = mid; }
+        int r = lo;
+        int local = (int)(g - tv.seed_off[r]);
+        const int32_t* iso = tv.intv_seed_off + (size_t)r * tv.intv_cap;
+        int n = tv.n_intv[r];
+        lo = 0; hi = n;
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (iso[mid] <= local) lo = mid; else hi = mid; }
+        Intv p = tv.intv[(size_t)r * tv.intv_cap + lo];
+        int64_t step = p.size > (uint64_t)(int64_t)opt.max_occ ? (int64_t)(p.size / (uint64_t)opt.max_occ) : 1;
+        int64_t k = (int64_t)(local - iso[lo]) * step;
+        Seed s;
+        s.rbeg = (int64_t)sa_lookup(ix, p.x0 + (uint64_t)k, n_lf); ++n_sa;
+        s.qbeg = (int32_t)(p.info >> 32);
+        s.len = s.score = (int32_t)((uint32_t)p.info - (uint32_t)(p.info >> 32));
+        s.next = -1;
+        tv.seeds[g] = s;
+        tv.seed_rid[g] = bns_intv2rid(ix, s.rbeg, s.rbeg + s.len);
+    }
+    unsigned long long a = n_lf, b = n_sa;
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
+    if ((threadIdx.x & 63) == 0) { count_add(&tv.cnt->n_lf, a); count_add(&tv.cnt->n_sa, b); }
+}
+
+void launch_encode(hipStream_t st, uint8_t* seq, int64_t n_bytes)
+{
+    if (n_bytes <= 0) return;
+    int64_t nb = (n_bytes + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_encode, dim3((unsigned)nb), dim3(256), 0, st, seq, n_bytes);
+}
+void launch_seed(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv)
+{
+    if (tv.n_reads <= 0) return;
+    hipLaunchKernelGGL(k_seed, dim3((tv.n_reads + 63) / 64), dim3(64), 0, st, ix, opt, tv);
+}
+void launch_scan(hipStream_t st, const int32_t* in, int64_t* out, int n)
+{
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, in, out, n);
+}
+void launch_sa(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, int64_t n_occ)
+{
+    if (n_occ <= 0) return;
+    hipLaunchKernelGGL(k_sa, dim3((unsigned)((n_occ + 255) / 256)), dim3(256), 0, st, ix, opt, tv, n_occ);
+}

@@ -1,0 +1,503 @@
+// pipeline.cpp -- host side of the library: index residency in HBM, request upload, the
+// tile loop that drives the kernels, result download, and the jnibwa_* C ABI.
+//
+// Drop-in boundary: reference src/main/c/jnibwa.c:126-235 (every exported function cites its
+// counterpart in include/bwamem_hip.h).  The device pipeline replaces the single upstream call
+// mem_process_seqs at jnibwa.c:214.  There is no host fallback: every stage of the hot path
+// runs as a HIP kernel and any device error makes the call return NULL.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <unistd.h>
+#include <fcntl.h>
+#include <errno.h>
+#include <sys/stat.h>
+#include <sys/mman.h>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include "bwamem_types.h"
+#include "kernels.h"
+#include "index_io.h"
+#include "../../include/bwamem_hip.h"
+
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    fprintf(stderr, "[bwamem_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return false; } } while (0)
+
+// ------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    bool ensure(size_t n) {
+        if (n <= bytes) return true;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        n += n / 8 + 256;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) { fprintf(stderr, "[bwamem_hip] hipMalloc(%zu) failed: %s\n", n, hipGetErrorString(e)); p = nullptr; return false; }
+        bytes = n;
+        return true;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+struct Stats {
+    std::mutex mu;
+    bool enabled = false;
+    bwamem_stats_t s;
+    Stats() { memset(&s, 0, sizeof s); }
+};
+static Stats g_stats;
+static int g_device = 0;
+
+enum KernelId { K_ENCODE, K_SEED, K_SA, K_CHAIN, K_EXTEND, K_POST, K_FINAL, K_PACK, K_OTHER, K_N };
+
+struct Timed { KernelId id; hipEvent_t a, b; };
+
+struct Workspace {
+    int T = 0, L = 0, intv_cap = 0, smem_cap = 0, out_cap = 0;
+    int64_t seed_cap = 0, post_per_read = 0;
+    DevBuf intv, n_intv, smem, l_rep, n_seeds, seed_off, intv_seed_off;
+    DevBuf seeds, seed_rid, cseeds, chains, chain_store, n_chains, bt_nodes, srt, regs, n_regs;
+    DevBuf out, out_len, out_off, post, err, cnt;
+    hipStream_t stream = nullptr;
+    std::vector<Timed> timed;
+
+    bool ensure_reads(int T_, int L_, int intv_cap_, int out_cap_, int64_t post_per_read_) {
+        T = T_; L = L_; intv_cap = intv_cap_; smem_cap = L_ + 2; out_cap = out_cap_; post_per_read = post_per_read_;
+        size_t t = (size_t)T;
+        return intv.ensure(t * intv_cap * sizeof(Intv)) && n_intv.ensure(t * 4) && smem.ensure(t * 3 * smem_cap * sizeof(Intv))
+            && l_rep.ensure(t * 4) && n_seeds.ensure(t * 4) && seed_off.ensure((t + 1) * 8) && intv_seed_off.ensure(t * intv_cap * 4)
+            && n_chains.ensure(t * 4) && n_regs.ensure(t * 4) && out.ensure(t * out_cap) && out_len.ensure(t * 4)
+            && out_off.ensure((t + 1) * 8) && post.ensure(t * (size_t)post_per_read) && err.ensure(64) && cnt.ensure(sizeof(DevCounters));
+    }
+    bool ensure_seeds(int64_t n) {
+        seed_cap = n;
+        size_t s = (size_t)n + 16;
+        return seeds.ensure(s * sizeof(Seed)) && seed_rid.ensure(s * 4) && cseeds.ensure(s * sizeof(Seed)) && chains.ensure(s * sizeof(Chain))
+            && chain_store.ensure(s * sizeof(Chain)) && bt_nodes.ensure((s / 4 + 3 * (size_t)T + 16) * 22 * 4) && srt.ensure(s * 8)
+            && regs.ensure(s * sizeof(AlnReg));
+    }
+    void release() {
+        DevBuf* all[] = { &intv, &n_intv, &smem, &l_rep, &n_seeds, &seed_off, &intv_seed_off, &seeds, &seed_rid, &cseeds, &chains,
+                          &chain_store, &n_chains, &bt_nodes, &srt, &regs, &n_regs, &out, &out_len, &out_off, &post, &err, &cnt };
+        for (DevBuf* b : all) b->release();
+        if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+    }
+    TileView view() const {
+        TileView tv; memset(&tv, 0, sizeof tv);
+        tv.intv_cap = intv_cap; tv.intv = intv.as<Intv>(); tv.n_intv = n_intv.as<int32_t>();
+        tv.smem_scratch = smem.as<Intv>(); tv.smem_cap = smem_cap; tv.l_rep = l_rep.as<int32_t>();
+        tv.n_seeds = n_seeds.as<int32_t>(); tv.seed_off = seed_off.as<int64_t>(); tv.intv_seed_off = intv_seed_off.as<int32_t>();
+        tv.seeds = seeds.as<Seed>(); tv.seed_rid = seed_rid.as<int32_t>(); tv.cseeds = cseeds.as<Seed>();
+        tv.chains = chains.as<Chain>(); tv.n_chains = n_chains.as<int32_t>(); tv.bt_nodes = bt_nodes.as<int32_t>();
+        tv.srt = srt.as<uint64_t>(); tv.regs = regs.as<AlnReg>(); tv.n_regs = n_regs.as<int32_t>();
+        tv.out_cap = out_cap; tv.out = out.as<uint8_t>(); tv.out_len = out_len.as<int32_t>(); tv.out_off = out_off.as<int64_t>();
+        tv.post_scratch = post.as<uint8_t>(); tv.post_scratch_per_read = post_per_read;
+        tv.err = err.as<int32_t>(); tv.cnt = cnt.as<DevCounters>();
+        return tv;
+    }
+};
+
+struct bwaidx_s {
+    uint8_t* mem = nullptr; size_t l_mem = 0; bool mmapped = false;
+    HostIndex h;
+    int device = 0;
+    DevIndex d;
+    DevBuf d_bwt, d_sa, d_pac, d_ann_off, d_ann_len, d_ann_alt, d_name_off, d_names, d_log;
+    std::mutex mu;                  // one call at a time per index/device
+    Workspace ws;
+};
+
+struct TileOut { uint8_t* d = nullptr; size_t bytes = 0; };
+
+struct bwamem_batch_s {
+    bwaidx_s* idx = nullptr;
+    uint32_t n_reads = 0;
+    size_t n_bytes = 0;
+    DevBuf d_seq, d_off;
+    std::vector<int64_t> h_off;
+    std::vector<TileOut> tiles;
+    size_t result_bytes = 0;
+    bool encoded = false;
+};
+
+static const int LOG_TAB_N = 1 << 20;
+
+// ------------------------------------------------------------------------------------------ index
+static bool upload_index(bwaidx_s* ix)
+{
+    HIP_OK(hipSetDevice(ix->device));
+    const HostIndex& h = ix->h;
+    const int n = (int)h.contigs.size();
+    size_t bwt_bytes = ((size_t)h.bwt_size * 4 + 127) & ~(size_t)63;   // whole 64-byte lines, plus slack for the last block
+    if (!ix->d_bwt.ensure(bwt_bytes) || !ix->d_sa.ensure((size_t)h.n_sa * 8) || !ix->d_pac.ensure((size_t)(h.l_pac / 4 + 1) + 16)) return false;
+    HIP_OK(hipMemset(ix->d_bwt.p, 0, ix->d_bwt.bytes));
+    HIP_OK(hipMemcpy(ix->d_bwt.p, h.bwt, (size_t)h.bwt_size * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(ix->d_sa.p, h.sa, (size_t)h.n_sa * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(ix->d_pac.p, h.pac, (size_t)(h.l_pac / 4 + 1), hipMemcpyHostToDevice));
+    std::vector<int64_t> off(n); std::vector<int32_t> len(n), alt(n), noff(n + 1);
+    std::string names;
+    for (int i = 0; i < n; ++i) {
+        off[i] = h.contigs[i].offset; len[i] = h.contigs[i].len; alt[i] = h.contigs[i].is_alt;
+        noff[i] = (int32_t)names.size();
+        names += h.contigs[i].name; names.push_back('\0');
+    }
+    noff[n] = (int32_t)names.size();
+    if (!ix->d_ann_off.ensure((size_t)n * 8 + 8) || !ix->d_ann_len.ensure((size_t)n * 4 + 4) || !ix->d_ann_alt.ensure((size_t)n * 4 + 4)
+        || !ix->d_name_off.ensure((size_t)(n + 1) * 4) || !ix->d_names.ensure(names.size() + 1) || !ix->d_log.ensure((size_t)LOG_TAB_N * 8)) return false;
+    HIP_OK(hipMemcpy(ix->d_ann_off.p, off.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(ix->d_ann_len.p, len.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(ix->d_ann_alt.p, alt.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(ix->d_name_off.p, noff.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(ix->d_names.p, names.data(), names.size(), hipMemcpyHostToDevice));
+    {   // log() stays a host (glibc) function: decisions that depend on it read this table
+        std::vector<double> lt(LOG_TAB_N);
+        for (int i = 0; i < LOG_TAB_N; ++i) lt[i] = log((double)i);
+        HIP_OK(hipMemcpy(ix->d_log.p, lt.data(), (size_t)LOG_TAB_N * 8, hipMemcpyHostToDevice));
+    }
+    DevIndex& d = ix->d;
+    memset(&d, 0, sizeof d);
+    d.bwt = ix->d_bwt.as<uint32_t>(); d.sa = ix->d_sa.as<uint64_t>(); d.pac = ix->d_pac.as<uint8_t>();
+    d.ann_offset = ix->d_ann_off.as<int64_t>(); d.ann_len = ix->d_ann_len.as<int32_t>(); d.ann_is_alt = ix->d_ann_alt.as<int32_t>();
+    d.ann_name_off = ix->d_name_off.as<int32_t>(); d.names = ix->d_names.as<char>(); d.log_tab = ix->d_log.as<double>();
+    d.primary = h.primary; for (int i = 0; i < 5; ++i) d.L2[i] = h.L2[i];
+    d.seq_len = h.seq_len; d.l_pac = h.l_pac; d.n_seqs = n; d.sa_intv = h.sa_intv; d.log_tab_n = LOG_TAB_N;
+    return true;
+}
+
+static void free_index(bwaidx_s* ix)
+{
+    (void)hipSetDevice(ix->device);
+    DevBuf* all[] = { &ix->d_bwt, &ix->d_sa, &ix->d_pac, &ix->d_ann_off, &ix->d_ann_len, &ix->d_ann_alt, &ix->d_name_off, &ix->d_names, &ix->d_log };
+    for (DevBuf* b : all) b->release();
+    ix->ws.release();
+}
+
+// ------------------------------------------------------------------------------------------ timing
+static void timed_begin(Workspace& ws, KernelId id)
+{
+    if (!g_stats.enabled) return;
+    Timed t; t.id = id;
+    if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return;
+    (void)hipEventRecord(t.a, ws.stream);
+    ws.timed.push_back(t);
+}
+static void timed_end(Workspace& ws)
+{
+    if (!g_stats.enabled || ws.timed.empty()) return;
+    (void)hipEventRecord(ws.timed.back().b, ws.stream);
+}
+static void timed_collect(Workspace& ws)
+{
+    if (ws.timed.empty()) return;
+    std::lock_guard<std::mutex> lk(g_stats.mu);
+    for (Timed& t : ws.timed) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            double* slot[K_N] = { &g_stats.s.ms_encode, &g_stats.s.ms_seed, &g_stats.s.ms_sa, &g_stats.s.ms_chain, &g_stats.s.ms_extend,
+                                  &g_stats.s.ms_post, &g_stats.s.ms_final, &g_stats.s.ms_pack, &g_stats.s.ms_other };
+            *slot[t.id] += ms;
+            if (t.id == K_SEED) ++g_stats.s.n_launch_seed;
+            if (t.id == K_SA) ++g_stats.s.n_launch_sa;
+            if (t.id == K_EXTEND) ++g_stats.s.n_launch_extend;
+        }
+        (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b);
+    }
+    ws.timed.clear();
+}
+#define TIMED(ws, id, call) do { timed_begin(ws, id); call; timed_end(ws); } while (0)
+
+// ------------------------------------------------------------------------------------------ tile loop
+static int64_t post_bytes_per_read(int L, const MemOpt& opt)
+{
+    int64_t ncol = std::min<int64_t>(L, 2 * ((int64_t)opt.w << 2) + 1);
+    int64_t tl = 3 * (int64_t)L + 64;
+    int64_t fixed = (int64_t)2 * (L + 2) * 4 + (int64_t)(4 * L + 16) * 4 + (8 * L + 32);
+    return ((fixed + ncol * tl) + 63) & ~(int64_t)63;
+}
+
+static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, bwamem_batch_s* b, int64_t read_id0)
+{
+    (void)pes;
+    HIP_OK(hipSetDevice(ix->device));
+    Workspace& ws = ix->ws;
+    if (!ws.stream) HIP_OK(hipStreamCreate(&ws.stream));
+    for (TileOut& t : b->tiles) if (t.d) (void)hipFree(t.d);
+    b->tiles.clear(); b->result_bytes = 0;
+    if (opt.flag & MEM_F_PE) { fprintf(stderr, "[bwamem_hip] paired-end mode (MEM_F_PE) is not implemented on the device path yet\n"); return false; }
+    if (b->n_reads == 0) return true;
+    if (!b->encoded) {
+        TIMED(ws, K_ENCODE, launch_encode(ws.stream, b->d_seq.as<uint8_t>(), (int64_t)b->n_bytes));
+        b->encoded = true;
+    }
+    const char* env_t = getenv("BWAMEM_HIP_TILE");
+    int intv_cap_scale = 1, out_cap = 512;
+    int64_t seed_cap_hint = 0;
+    uint32_t r0 = 0;
+    while (r0 < b->n_reads) {
+        // tile size from a device-memory budget
+        int64_t budget = (int64_t)24 << 30;
+        int L0 = 1;
+        uint32_t r1 = r0;
+        int64_t per_read = 0;
+        uint32_t max_T = env_t ? (uint32_t)atoi(env_t) : 262144u;
+        while (r1 < b->n_reads && r1 - r0 < max_T) {
+            int len = (int)(b->h_off[r1 + 1] - b->h_off[r1] - 1);
+            int L1 = std::max(L0, len);
+            int icap = std::max(64, L1 + 8) * intv_cap_scale;
+            int64_t pr = (int64_t)icap * (sizeof(Intv) + 4) + 3 * (int64_t)(L1 + 2) * sizeof(Intv) + out_cap + post_bytes_per_read(L1, opt) + 64 * 300;
+            if (r1 > r0 && pr * (int64_t)(r1 - r0 + 1) > budget) break;
+            L0 = L1; per_read = pr; ++r1;
+        }
+        (void)per_read;
+        const int T = (int)(r1 - r0), L = L0;
+        int intv_cap = std::max(64, L + 8) * intv_cap_scale;
+        bool tile_done = false;
+        int attempts = 0;
+        while (!tile_done) {
+            if (++attempts > 8) { fprintf(stderr, "[bwamem_hip] tile could not be sized after 8 attempts\n"); return false; }
+            if (!ws.ensure_reads(T, L, intv_cap, out_cap, post_bytes_per_read(L, opt))) return false;
+            if (!ws.ensure_seeds(std::max<int64_t>(seed_cap_hint, (int64_t)T * 16))) return false;
+            TileView tv = ws.view();
+            tv.n_reads = T; tv.max_len = L; tv.read_id0 = read_id0 + r0;
+            tv.seq = b->d_seq.as<uint8_t>(); tv.seq_off = b->d_off.as<int64_t>() + r0;
+            HIP_OK(hipMemsetAsync(ws.err.p, 0, 64, ws.stream));
+            HIP_OK(hipMemsetAsync(ws.cnt.p, 0, sizeof(DevCounters), ws.stream));
+            TIMED(ws, K_SEED, launch_seed(ws.stream, ix->d, opt, tv));
+            TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_seeds, tv.seed_off, T));
+            int64_t n_occ = 0; int32_t err = 0;
+            HIP_OK(hipMemcpyAsync(&n_occ, tv.seed_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
+            HIP_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
+            HIP_OK(hipStreamSynchronize(ws.stream));
+            HIP_OK(hipGetLastError());
+            if (err & ERR_INTV_CAP) { intv_cap *= 2; intv_cap_scale *= 2; { std::lock_guard<std::mutex> lk(g_stats.mu); ++g_stats.s.n_retries; } continue; }
+            if (n_occ > ws.seed_cap) {
+                seed_cap_hint = n_occ + n_occ / 4;
+                if (!ws.ensure_seeds(seed_cap_hint)) return false;
+                tv = ws.view();
+                tv.n_reads = T; tv.max_len = L; tv.read_id0 = read_id0 + r0;
+                tv.seq = b->d_seq.as<uint8_t>(); tv.seq_off = b->d_off.as<int64_t>() + r0;
+            }
+            TIMED(ws, K_SA, launch_sa(ws.stream, ix->d, opt, tv, n_occ));
+            TIMED(ws, K_CHAIN, launch_chain(ws.stream, ix->d, opt, tv, ws.chain_store.as<Chain>()));
+            TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
+            TIMED(ws, K_POST, launch_post1(ws.stream, ix->d, opt, tv));
+            TIMED(ws, K_FINAL, launch_final_se(ws.stream, ix->d, opt, tv));
+            TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.out_len, tv.out_off, T));
+            int64_t out_total = 0;
+            DevCounters hc;
+            HIP_OK(hipMemcpyAsync(&out_total, tv.out_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
+            HIP_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
+            HIP_OK(hipMemcpyAsync(&hc, tv.cnt, sizeof hc, hipMemcpyDeviceToHost, ws.stream));
+            HIP_OK(hipStreamSynchronize(ws.stream));
+            HIP_OK(hipGetLastError());
+            if (err) {
+                { std::lock_guard<std::mutex> lk(g_stats.mu); ++g_stats.s.n_retries; }
+                if (err & ERR_LONG_READ) { fprintf(stderr, "[bwamem_hip] reads long enough to need seed re-scoring (mem_flt_chained_seeds) are not supported on the device path yet\n"); return false; }
+                if (err & ERR_BTREE) { fprintf(stderr, "[bwamem_hip] internal error: chain B-tree pool exhausted\n"); return false; }
+                if (err & (ERR_SCRATCH | ERR_CIGAR_CAP)) { fprintf(stderr, "[bwamem_hip] internal error: post-processing scratch exhausted (err=%d)\n", err); return false; }
+                if (err & ERR_OUT_CAP) { out_cap *= 4; continue; }
+                fprintf(stderr, "[bwamem_hip] device error flags %d\n", err); return false;
+            }
+            TileOut to;
+            to.bytes = (size_t)out_total;
+            if (out_total > 0) {
+                HIP_OK(hipMalloc((void**)&to.d, (size_t)out_total));
+                TIMED(ws, K_PACK, launch_pack(ws.stream, tv, to.d));
+                HIP_OK(hipStreamSynchronize(ws.stream));
+                HIP_OK(hipGetLastError());
+            }
+            b->tiles.push_back(to);
+            b->result_bytes += to.bytes;
+            {
+                std::lock_guard<std::mutex> lk(g_stats.mu);
+                g_stats.s.n_reads += T; g_stats.s.n_ext += hc.n_ext; g_stats.s.n_lf += hc.n_lf; g_stats.s.n_sa += hc.n_sa;
+                g_stats.s.n_dp_cells += hc.n_dp_cells; ++g_stats.s.n_tiles;
+            }
+            timed_collect(ws);
+            tile_done = true;
+        }
+        r0 = r1;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int bwamem_hip_set_device(int device) { g_device = device; return hipSetDevice(device) == hipSuccess ? 0 : -1; }
+int bwamem_hip_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+
+void bwamem_hip_stats_enable(int on) { g_stats.enabled = on != 0; }
+void bwamem_hip_stats_reset(void) { std::lock_guard<std::mutex> lk(g_stats.mu); memset(&g_stats.s, 0, sizeof g_stats.s); }
+void bwamem_hip_stats_get(bwamem_stats_t* out) { std::lock_guard<std::mutex> lk(g_stats.mu); *out = g_stats.s; }
+
+void jnibwa_free(void* p) { free(p); }
+
+const char* jnibwa_getVersion(void) { return "bwamem-hip-gfx950 (behavioural target: lh3/bwa cb950614ce7217788780b9a8d445c64cd4d8f62e)"; }
+
+mem_opt_t* jnibwa_createDefaultOptions(void)
+{   // upstream mem_opt_init + bwa_fill_scmat (defaults: SURVEY.md App. A.5)
+    MemOpt* o = (MemOpt*)calloc(1, sizeof(MemOpt));
+    o->a = 1; o->b = 4; o->o_del = o->o_ins = 6; o->e_del = o->e_ins = 1;
+    o->w = 100; o->T = 30; o->zdrop = 100; o->pen_unpaired = 17; o->pen_clip5 = o->pen_clip3 = 5;
+    o->max_mem_intv = 20; o->min_seed_len = 19; o->split_width = 10; o->max_occ = 500; o->max_chain_gap = 10000;
+    o->max_ins = 10000; o->mask_level = 0.50f; o->drop_ratio = 0.50f; o->XA_drop_ratio = 0.80f; o->split_factor = 1.5f;
+    o->chunk_size = 10000000; o->n_threads = 1; o->max_XA_hits = 5; o->max_XA_hits_alt = 200; o->max_matesw = 50;
+    o->mask_level_redun = 0.95f; o->min_chain_weight = 0; o->max_chain_extend = 1 << 30;
+    o->mapQ_coef_len = 50; o->mapQ_coef_fac = (int)log((double)o->mapQ_coef_len);
+    int k = 0;
+    for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) o->mat[k++] = (int8_t)(i == j ? o->a : -o->b); o->mat[k++] = -1; }
+    for (int j = 0; j < 5; ++j) o->mat[k++] = -1;
+    return (mem_opt_t*)o;
+}
+
+int jnibwa_createReferenceIndex(const char* refFileName, const char* indexPrefix, const char* algoName)
+{
+    if (algoName && strcmp(algoName, "auto") && strcmp(algoName, "is") && strcmp(algoName, "rb2")) return -1;
+    std::string err;
+    if (!build_index_files(refFileName, indexPrefix, &err)) { fprintf(stderr, "[bwamem_hip] index build failed: %s\n", err.c_str()); return 1; }
+    return 0;
+}
+
+int jnibwa_createIndexFile(const char* refName, const char* imgName)
+{
+    std::string err;
+    std::vector<uint8_t> img = image_from_index_files(refName, &err);
+    if (img.empty()) { printf("Failed to load index %s: %s\n", refName, err.c_str()); return 2; }
+    int fd = open(imgName, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd == -1) { printf("Failed to open %s for writing: %s\n", imgName, strerror(errno)); return 2; }
+    size_t len = img.size();
+    const uint8_t* buf = img.data();
+    while (len) {
+        size_t to_write = std::min<size_t>(len, (size_t)1 << 30);
+        if (write(fd, buf, to_write) != (ssize_t)to_write) { printf("Failed to write %s: %s\n", imgName, strerror(errno)); close(fd); return 2; }
+        buf += to_write; len -= to_write;
+    }
+    if (close(fd) != 0) { printf("Failed to close %s: %s\n", imgName, strerror(errno)); return 2; }
+    return 0;
+}
+
+bwaidx_t* jnibwa_openIndex(int fd)
+{
+    struct stat st;
+    if (fstat(fd, &st) == -1) { close(fd); return 0; }
+    void* mem = mmap(0, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+    close(fd);
+    if (mem == MAP_FAILED) return 0;
+    bwaidx_s* ix = new bwaidx_s();
+    ix->mem = (uint8_t*)mem; ix->l_mem = (size_t)st.st_size; ix->mmapped = true; ix->device = g_device;
+    if (!parse_index_image(ix->mem, ix->l_mem, ix->h) || !upload_index(ix)) {
+        fprintf(stderr, "[bwamem_hip] cannot open index image (malformed image or no usable HIP device)\n");
+        free_index(ix);
+        munmap(mem, (size_t)st.st_size);
+        delete ix;
+        return 0;
+    }
+    return ix;
+}
+
+int jnibwa_destroyIndex(bwaidx_t* pIdx)
+{
+    if (!pIdx) return 0;
+    void* mem = pIdx->mem; size_t len = pIdx->l_mem;
+    free_index(pIdx);
+    delete pIdx;
+    return munmap(mem, len);
+}
+
+void* jnibwa_getRefContigNames(bwaidx_t* pIdx, size_t* pBufSize)
+{
+    const std::vector<ContigInfo>& c = pIdx->h.contigs;
+    size_t bufSize = 4 + 4 * c.size();
+    for (const ContigInfo& ci : c) bufSize += ci.name.size() + 1;   // the reference over-allocates by one byte per name (jnibwa.c:181)
+    char* bufMem = (char*)calloc(bufSize, 1);
+    *(int32_t*)bufMem = (int32_t)c.size();
+    char* p = bufMem + 4;
+    for (const ContigInfo& ci : c) {
+        *(int32_t*)p = (int32_t)ci.name.size(); p += 4;
+        memcpy(p, ci.name.data(), ci.name.size()); p += ci.name.size();
+    }
+    *pBufSize = bufSize;
+    return bufMem;
+}
+
+bwamem_batch_t* bwamem_hip_batch_upload(bwaidx_t* idx, const char* pSeq, size_t nBytes)
+{
+    if (!idx || !pSeq || nBytes < 4) return 0;
+    if (hipSetDevice(idx->device) != hipSuccess) return 0;
+    bwamem_batch_s* b = new bwamem_batch_s();
+    b->idx = idx;
+    memcpy(&b->n_reads, pSeq, 4);
+    const char* p = pSeq + 4; const char* end = pSeq + nBytes;
+    b->h_off.resize((size_t)b->n_reads + 1);
+    for (uint32_t i = 0; i < b->n_reads; ++i) {          // jnibwa.c:204-212 (strlen walk)
+        b->h_off[i] = p - (pSeq + 4);
+        const char* z = (const char*)memchr(p, 0, (size_t)(end - p));
+        if (!z) { fprintf(stderr, "[bwamem_hip] request buffer ends inside read %u\n", i); delete b; return 0; }
+        p = z + 1;
+    }
+    b->h_off[b->n_reads] = p - (pSeq + 4);
+    b->n_bytes = (size_t)b->h_off[b->n_reads];
+    bool ok = b->d_seq.ensure(b->n_bytes + 64) && b->d_off.ensure(((size_t)b->n_reads + 1) * 8);
+    ok = ok && hipMemcpy(b->d_seq.p, pSeq + 4, b->n_bytes, hipMemcpyHostToDevice) == hipSuccess
+            && hipMemcpy(b->d_off.p, b->h_off.data(), ((size_t)b->n_reads + 1) * 8, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { fprintf(stderr, "[bwamem_hip] request upload failed\n"); bwamem_hip_batch_free(b); return 0; }
+    return b;
+}
+
+int bwamem_hip_batch_align(bwaidx_t* idx, const mem_opt_t* opt, const mem_pestat_t* pes, bwamem_batch_t* b, int64_t read_id0)
+{
+    if (!idx || !opt || !b) return -1;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    MemOpt o; memcpy(&o, opt, sizeof o);
+    return align_batch(idx, o, (const MemPestat*)pes, b, read_id0) ? 0 : -1;
+}
+
+size_t bwamem_hip_batch_result_bytes(const bwamem_batch_t* b) { return b->result_bytes; }
+
+int bwamem_hip_batch_download(bwamem_batch_t* b, void* dst)
+{
+    if (hipSetDevice(b->idx->device) != hipSuccess) return -1;
+    uint8_t* p = (uint8_t*)dst;
+    for (const TileOut& t : b->tiles) {
+        if (t.bytes && hipMemcpy(p, t.d, t.bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        p += t.bytes;
+    }
+    return 0;
+}
+
+void bwamem_hip_batch_free(bwamem_batch_t* b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->idx->device);
+    for (TileOut& t : b->tiles) if (t.d) (void)hipFree(t.d);
+    b->d_seq.release(); b->d_off.release();
+    delete b;
+}
+
+void* jnibwa_createAlignments(bwaidx_t* pIdx, mem_opt_t* pOpts, mem_pestat_t* peStats, char* pSeq, size_t* pBufSize)
+{
+    if (pBufSize) *pBufSize = 0;
+    if (!pIdx || !pOpts || !pSeq) return 0;
+    // total request size: walk the NUL-terminated strings exactly as the reference does
+    uint32_t n; memcpy(&n, pSeq, 4);
+    size_t nBytes = 4;
+    { const char* p = pSeq + 4; for (uint32_t i = 0; i < n; ++i) p += strlen(p) + 1; nBytes = (size_t)(p - pSeq); }
+    bwamem_batch_t* b = bwamem_hip_batch_upload(pIdx, pSeq, nBytes);
+    if (!b) return 0;
+    void* res = 0;
+    if (bwamem_hip_batch_align(pIdx, pOpts, peStats, b, 0) == 0) {
+        size_t sz = bwamem_hip_batch_result_bytes(b);
+        res = malloc(sz ? sz : 1);
+        if (res && bwamem_hip_batch_download(b, res) != 0) { free(res); res = 0; }
+        if (res && pBufSize) *pBufSize = sz;
+    }
+    bwamem_hip_batch_free(b);
+    return res;
+}
+
+} // extern "C"

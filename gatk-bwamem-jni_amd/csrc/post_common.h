@@ -1,0 +1,526 @@
+// post_common.h -- device functions shared by the single-end and paired-end finalisation
+// kernels: global alignment + CIGAR/NM/MD, MAPQ, primary marking, XA, record writer.
+// Behavioural contract: SURVEY.md rows a14-a18 (see k_post.hip for the upstream names).
+#pragma once
+#include "dev_common.h"
+
+#define INT_MAX_ 2147483647
+#define MINUS_INF (-0x40000000)
+
+struct PostScratch {
+    int32_t* eh;  int eh_cap;        // (h,e) pairs
+    uint8_t* z;   int64_t z_cap;     // traceback matrix
+    uint32_t* cig; int cig_cap;      // CIGAR ops (slot 0 kept free for a leading clip)
+    char* md;     int md_cap;
+    int err;
+};
+
+DEV PostScratch post_scratch_for(const TileView& tv, int r)
+{
+    PostScratch S;
+    uint8_t* base = tv.post_scratch + (size_t)r * tv.post_scratch_per_read;
+    int L = tv.max_len;
+    S.eh_cap = 2 * (L + 2);
+    S.cig_cap = 4 * L + 16;
+    S.md_cap = 8 * L + 32;
+    S.eh = (int32_t*)base;                       base += (size_t)S.eh_cap * 4;
+    S.cig = (uint32_t*)base;                     base += (size_t)S.cig_cap * 4;
+    S.md = (char*)base;                          base += (size_t)S.md_cap;
+    S.z = base;
+    S.z_cap = tv.post_scratch_per_read - ((int64_t)S.eh_cap * 4 + (int64_t)S.cig_cap * 4 + S.md_cap);
+    S.err = 0;
+    return S;
+}
+
+struct OutBuf {
+    uint8_t* p; int cap, len; bool ovf;
+    __device__ void put32(int32_t v) { if (len + 4 > cap) { ovf = true; return; } *(int32_t*)(p + len) = v; len += 4; }
+    __device__ void putc(char c) { if (len + 1 > cap) { ovf = true; return; } p[len++] = (uint8_t)c; }
+    __device__ void pad4() { while (len & 3) putc(0); }
+    __device__ void putl(long v) {
+        char b[24]; int l = 0;
+        unsigned long x = v < 0 ? 0ul - (unsigned long)v : (unsigned long)v;
+        do { b[l++] = (char)('0' + x % 10); x /= 10; } while (x);
+        if (v < 0) b[l++] = '-';
+        while (l > 0) putc(b[--l]);
+    }
+};
+
+struct MdBuf {
+    char* s; int cap, l; bool ovf;
+    __device__ void putc(char c) { if (l + 1 >= cap) { ovf = true; return; } s[l++] = c; }
+    __device__ void putw(int v) {
+        char b[16]; int n = 0;
+        unsigned x = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+        do { b[n++] = (char)('0' + x % 10); x /= 10; } while (x);
+        if (v < 0) b[n++] = '-';
+        while (n > 0) putc(b[--n]);
+    }
+};
+
+// one alignment record (upstream mem_aln_t); cigar / md point into PostScratch
+struct AlnRec {
+    int64_t pos;
+    int rid, flag, is_rev, is_alt, mapq, NM, n_cigar;
+    const uint32_t* cigar;
+    const char* md; int l_md;
+    int score, sub, alt_sc;
+    int ref_len;                 // sum of M and D lengths (jnibwa.c:30-41 cigarRefLen)
+};
+
+struct MateInfo { int rid; int64_t pos; int is_rev; int ref_len; };
+
+struct SeqAcc {                  // query / target accessors with optional reversal (no copies)
+    const uint8_t* q; int qlen; int rev;
+    int64_t t0; int tlen;
+};
+DEV int acc_q(const SeqAcc& A, int j) { return A.q[A.rev ? A.qlen - 1 - j : j]; }
+DEV int acc_t(const DevIndex& ix, const SeqAcc& A, int i) { return ref_base2(ix, A.t0 + (A.rev ? A.tlen - 1 - i : i)); }
+
+// ksw_global2: banded global alignment, optional traceback into S.cig[1..]
+DEV int global_dp(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const SeqAcc& A, int w, bool want_cigar, int* n_cigar_)
+{
+    const int qlen = A.qlen, tlen = A.tlen;
+    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    int i, j, k, score, n_col;
+    if (n_cigar_) *n_cigar_ = 0;
+    n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    if (2 * (qlen + 1) > S.eh_cap || (want_cigar && (int64_t)n_col * tlen > S.z_cap)) { S.err |= ERR_SCRATCH; return 0; }
+    int32_t* eh = S.eh;
+    uint8_t* z = S.z;
+    eh[0] = 0; eh[1] = MINUS_INF;
+    for (j = 1; j <= qlen && j <= w; ++j) { eh[2 * j] = -(o_ins + e_ins * j); eh[2 * j + 1] = MINUS_INF; }
+    for (; j <= qlen; ++j) eh[2 * j] = eh[2 * j + 1] = MINUS_INF;
+    for (i = 0; i < tlen; ++i) {
+        int32_t f = MINUS_INF, h1, beg, end, t;
+        const int tb = acc_t(ix, A, i);
+        uint8_t* zi = z + (int64_t)i * n_col;
+        beg = i > w ? i - w : 0;
+        end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        h1 = beg == 0 ? -(o_del + e_del * (i + 1)) : MINUS_INF;
+        for (j = beg; j < end; ++j) {
+            int32_t h, M = eh[2 * j], e = eh[2 * j + 1];
+            uint8_t d;
+            eh[2 * j] = h1;
+            M += opt.mat[tb * 5 + acc_q(A, j)];
+            d = M >= e ? 0 : 1;
+            h = M >= e ? M : e;
+            d = h >= f ? d : 2;
+            h = h >= f ? h : f;
+            h1 = h;
+            t = M - oe_del;
+            e -= e_del;
+            d |= e > t ? 1 << 2 : 0;
+            e  = e > t ? e : t;
+            eh[2 * j + 1] = e;
+            t = M - oe_ins;
+            f -= e_ins;
+            d |= f > t ? 2 << 4 : 0;
+            f  = f > t ? f : t;
+            if (want_cigar) zi[j - beg] = d;
+        }
+        eh[2 * end] = h1; eh[2 * end + 1] = MINUS_INF;
+    }
+    score = eh[2 * qlen];
+    if (want_cigar) {   // backtrack; ops are produced end-to-start, then reversed in place
+        int n = 0, which = 0;
+        uint32_t* cigar = S.cig + 1;
+        const int cap = S.cig_cap - 2;
+        i = tlen - 1; k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+        while (i >= 0 && k >= 0) {
+            int op;
+            which = z[(int64_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+            if (which == 0) { op = 0; --i; --k; }
+            else if (which == 1) { op = 2; --i; }
+            else { op = 1; --k; }
+            if (n == 0 || op != (int)(cigar[n - 1] & 0xf)) { if (n >= cap) { S.err |= ERR_CIGAR_CAP; return score; } cigar[n++] = 1u << 4 | (uint32_t)op; }
+            else cigar[n - 1] += 1u << 4;
+        }
+        if (i >= 0) { if (n == 0 || 2 != (int)(cigar[n - 1] & 0xf)) { if (n >= cap) { S.err |= ERR_CIGAR_CAP; return score; } cigar[n++] = (uint32_t)(i + 1) << 4 | 2; } else cigar[n - 1] += (uint32_t)(i + 1) << 4; }
+        if (k >= 0) { if (n == 0 || 1 != (int)(cigar[n - 1] & 0xf)) { if (n >= cap) { S.err |= ERR_CIGAR_CAP; return score; } cigar[n++] = (uint32_t)(k + 1) << 4 | 1; } else cigar[n - 1] += (uint32_t)(k + 1) << 4; }
+        for (i = 0; i < n >> 1; ++i) { uint32_t tmp = cigar[i]; cigar[i] = cigar[n - 1 - i]; cigar[n - 1 - i] = tmp; }
+        *n_cigar_ = n;
+    }
+    return score;
+}
+
+// bwa_gen_cigar2: returns false when upstream would return a NULL cigar.  CIGAR lands in
+// S.cig[1..1+n), MD in S.md (NUL-terminated, length *l_md) when want_cigar.
+DEV bool gen_cigar2(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int w_, int l_query, const uint8_t* query,
+                    int64_t rb, int64_t re, int* score, bool want_cigar, int* n_cigar, int* NM, int* l_md = 0)
+{
+    const int64_t l_pac = ix.l_pac;
+    if (n_cigar) *n_cigar = 0;
+    if (NM) *NM = -1;
+    if (l_md) *l_md = 0;
+    if (want_cigar) S.md[0] = 0;
+    if (l_query <= 0 || rb >= re || (rb < l_pac && re > l_pac)) return false;
+    if (re > l_pac << 1 || rb < 0) return false;       // upstream: clipped fetch length != re - rb
+    SeqAcc A; A.q = query; A.qlen = l_query; A.rev = rb >= l_pac; A.t0 = rb; A.tlen = (int)(re - rb);
+    const int rlen = A.tlen;
+    int n_cig = 0;
+    if (l_query == re - rb && w_ == 0) {               // no gap: no DP
+        int sc = 0;
+        for (int i = 0; i < l_query; ++i) sc += opt.mat[acc_t(ix, A, i) * 5 + acc_q(A, i)];
+        *score = sc;
+        if (want_cigar) { S.cig[1] = (uint32_t)l_query << 4; n_cig = 1; }
+    } else {
+        int w, max_gap, max_ins, max_del, min_w, d;
+        max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+        max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+        max_gap = max_ins > max_del ? max_ins : max_del;
+        max_gap = max_gap > 1 ? max_gap : 1;
+        d = rlen - l_query; d = d < 0 ? -d : d;
+        w = (max_gap + d + 1) >> 1;
+        w = w < w_ ? w : w_;
+        min_w = d + 3;
+        w = w > min_w ? w : min_w;
+        *score = global_dp(ix, opt, S, A, w, want_cigar, &n_cig);
+    }
+    if (want_cigar) {
+        if (n_cigar) *n_cigar = n_cig;
+        if (NM) {                                        // NM and MD
+            const uint32_t* cigar = S.cig + 1;
+            int k, x, y, u, n_mm = 0, n_gap = 0;
+            const char* int2base = rb < l_pac ? "ACGTN" : "TGCAN";
+            MdBuf md; md.s = S.md; md.cap = S.md_cap; md.l = 0; md.ovf = false;
+            for (k = 0, x = y = u = 0; k < n_cig; ++k) {
+                int op = cigar[k] & 0xf, len = (int)(cigar[k] >> 4);
+                if (op == 0) {
+                    for (int i = 0; i < len; ++i) {
+                        int tb = acc_t(ix, A, y + i);
+                        if (acc_q(A, x + i) != tb) { md.putw(u); md.putc(int2base[tb]); ++n_mm; u = 0; }
+                        else ++u;
+                    }
+                    x += len; y += len;
+                } else if (op == 2) {
+                    if (k > 0 && k < n_cig - 1) {
+                        md.putw(u); md.putc('^');
+                        for (int i = 0; i < len; ++i) md.putc(int2base[acc_t(ix, A, y + i)]);
+                        u = 0; n_gap += len;
+                    }
+                    y += len;
+                } else if (op == 1) { x += len; n_gap += len; }
+            }
+            md.putw(u);
+            md.s[md.l] = 0;
+            if (md.ovf) S.err |= ERR_CIGAR_CAP;
+            *NM = n_mm + n_gap;
+            if (l_md) *l_md = md.l;
+        }
+    }
+    return true;
+}
+
+DEV int approx_mapq_se(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const AlnReg& a)
+{
+    int mapq, l, sub = a.sub ? a.sub : opt.min_seed_len * opt.a;
+    double identity;
+    sub = a.csub > sub ? a.csub : sub;
+    if (sub >= a.score) return 0;
+    l = a.qe - a.qb > a.re - a.rb ? a.qe - a.qb : (int)(a.re - a.rb);
+    identity = 1. - (double)(l * opt.a - a.score) / (opt.a + opt.b) / l;
+    if (l < 0 || l >= ix.log_tab_n || a.seedcov < 0 || a.seedcov >= ix.log_tab_n || a.sub_n + 1 >= ix.log_tab_n) { S.err |= ERR_SCRATCH; return 0; }
+    if (a.score == 0) {
+        mapq = 0;
+    } else if (opt.mapQ_coef_len > 0) {
+        double tmp;
+        tmp = l < opt.mapQ_coef_len ? 1. : opt.mapQ_coef_fac / ix.log_tab[l];
+        tmp *= identity * identity;
+        mapq = (int)(6.02 * (a.score - sub) / opt.a * tmp * tmp + .499);
+    } else {
+        mapq = (int)(30.0 * (1. - (double)sub / a.score) * ix.log_tab[a.seedcov] + .499);
+        mapq = identity < 0.95 ? (int)(mapq * identity * identity + .499) : mapq;
+    }
+    if (a.sub_n > 0) mapq -= (int)(4.343 * ix.log_tab[a.sub_n + 1] + .499);
+    if (mapq > 60) mapq = 60;
+    if (mapq < 0) mapq = 0;
+    mapq = (int)(mapq * (1. - a.frac_rep) + .499);
+    return mapq;
+}
+
+DEV int infer_bw(int l1, int l2, int score, int a, int q, int r)
+{
+    int w, d;
+    if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
+    w = (int)((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.);
+    d = l1 - l2; d = d < 0 ? -d : d;
+    if (w < d) w = d;
+    return w;
+}
+
+// mem_reg2aln; ar == 0 gives the unmapped record
+DEV AlnRec reg2aln(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int l_query, const uint8_t* query, const AlnReg* ar)
+{
+    AlnRec a;
+    a.pos = 0; a.rid = 0; a.flag = 0; a.is_rev = 0; a.is_alt = 0; a.mapq = 0; a.NM = 0; a.n_cigar = 0;
+    a.cigar = S.cig + 1; a.md = S.md; a.l_md = 0; a.score = a.sub = a.alt_sc = 0; a.ref_len = 0;
+    S.md[0] = 0;
+    if (ar == 0 || ar->rb < 0 || ar->re < 0) { a.rid = -1; a.pos = -1; a.flag |= 0x4; return a; }
+    int i, w2, tmp, NM = -1, score = 0, is_rev, last_sc = -(1 << 30), n_cigar = 0, l_md = 0;
+    const int qb = ar->qb, qe = ar->qe;
+    const int64_t rb = ar->rb, re = ar->re;
+    a.mapq = ar->secondary < 0 ? approx_mapq_se(ix, opt, S, *ar) : 0;
+    if (ar->secondary >= 0) a.flag |= 0x100;
+    tmp = infer_bw(qe - qb, (int)(re - rb), ar->truesc, opt.a, opt.o_del, opt.e_del);
+    w2  = infer_bw(qe - qb, (int)(re - rb), ar->truesc, opt.a, opt.o_ins, opt.e_ins);
+    w2 = w2 > tmp ? w2 : tmp;
+    if (w2 > opt.w) w2 = w2 < ar->w ? w2 : ar->w;
+    i = 0;
+    do {
+        w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+        gen_cigar2(ix, opt, S, w2, qe - qb, query + qb, rb, re, &score, true, &n_cigar, &NM, &l_md);
+        if (score == last_sc || w2 == opt.w << 2) break;
+        last_sc = score;
+        w2 <<= 1;
+    } while (++i < 3 && score < ar->truesc - opt.a);
+    a.NM = NM & 0x3fffff;                                   // NM:22 bit-field upstream
+    int64_t pos = bns_depos(ix, rb < ix.l_pac ? rb : re - 1, is_rev);
+    a.is_rev = is_rev;
+    uint32_t* cig = S.cig + 1;
+    if (n_cigar > 0) {                                      // squeeze out a leading or trailing deletion
+        if ((cig[0] & 0xf) == 2) { pos += cig[0] >> 4; --n_cigar; ++cig; }
+        else if ((cig[n_cigar - 1] & 0xf) == 2) --n_cigar;
+    }
+    if (qb != 0 || qe != l_query) {                         // soft clips (op 3 upstream)
+        int clip5 = is_rev ? l_query - qe : qb;
+        int clip3 = is_rev ? qb : l_query - qe;
+        if (clip5) { --cig; cig[0] = (uint32_t)clip5 << 4 | 3; ++n_cigar; }
+        if (clip3) { if (n_cigar + (int)(cig - S.cig) >= S.cig_cap) { S.err |= ERR_CIGAR_CAP; } else cig[n_cigar++] = (uint32_t)clip3 << 4 | 3; }
+    }
+    a.cigar = cig; a.n_cigar = n_cigar; a.md = S.md; a.l_md = l_md;
+    for (i = 0; i < n_cigar; ++i) { int op = cig[i] & 0xf; if (op == 0 || op == 2) a.ref_len += (int)(cig[i] >> 4); }
+    a.rid = bns_pos2rid(ix, pos);
+    a.pos = pos - ix.ann_offset[a.rid];
+    a.score = ar->score; a.sub = ar->sub > ar->csub ? ar->sub : ar->csub;
+    a.is_alt = ar->is_alt; a.alt_sc = ar->alt_sc;
+    return a;
+}
+
+// ------------------------------------------------------------------ primary marking (a14)
+struct RegHLt  { __device__ bool operator()(const AlnReg& a, const AlnReg& b) const {
+    return a.score > b.score || (a.score == b.score && (a.is_alt < b.is_alt || (a.is_alt == b.is_alt && a.hash < b.hash))); } };
+struct RegHLt2 { __device__ bool operator()(const AlnReg& a, const AlnReg& b) const {
+    return a.is_alt < b.is_alt || (a.is_alt == b.is_alt && (a.score > b.score || (a.score == b.score && a.hash < b.hash))); } };
+
+DEV void mark_primary_core(const MemOpt& opt, int n, AlnReg* a, int32_t* z)
+{
+    int i, k, nz = 0, tmp;
+    tmp = opt.a + opt.b;
+    tmp = opt.o_del + opt.e_del > tmp ? opt.o_del + opt.e_del : tmp;
+    tmp = opt.o_ins + opt.e_ins > tmp ? opt.o_ins + opt.e_ins : tmp;
+    z[nz++] = 0;
+    for (i = 1; i < n; ++i) {
+        for (k = 0; k < nz; ++k) {
+            int j = z[k];
+            int b_max = a[j].qb > a[i].qb ? a[j].qb : a[i].qb;
+            int e_min = a[j].qe < a[i].qe ? a[j].qe : a[i].qe;
+            if (e_min > b_max) {
+                int min_l = a[i].qe - a[i].qb < a[j].qe - a[j].qb ? a[i].qe - a[i].qb : a[j].qe - a[j].qb;
+                if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level) {
+                    if (a[j].sub == 0) a[j].sub = a[i].score;
+                    if (a[j].score - a[i].score <= tmp && (a[j].is_alt || !a[i].is_alt)) ++a[j].sub_n;
+                    break;
+                }
+            }
+        }
+        if (k == nz) z[nz++] = i;
+        else a[i].secondary = z[k];
+    }
+}
+
+DEV int mark_primary_se(const MemOpt& opt, int n, AlnReg* a, int64_t id, int32_t* z)
+{
+    int i, n_pri;
+    if (n == 0) return 0;
+    for (i = n_pri = 0; i < n; ++i) {
+        a[i].sub = a[i].alt_sc = 0; a[i].secondary = a[i].secondary_all = -1; a[i].hash = hash_64((uint64_t)(id + i));
+        if (!a[i].is_alt) ++n_pri;
+    }
+    ks_introsort((size_t)n, a, RegHLt());
+    mark_primary_core(opt, n, a, z);
+    for (i = 0; i < n; ++i) {
+        AlnReg* p = &a[i];
+        p->secondary_all = i;
+        if (!p->is_alt && p->secondary >= 0 && a[p->secondary].is_alt) p->alt_sc = a[p->secondary].score;
+    }
+    if (n_pri >= 0 && n_pri < n) {
+        if (n_pri > 0) ks_introsort((size_t)n, a, RegHLt2());
+        for (i = 0; i < n; ++i) z[a[i].secondary_all] = i;
+        for (i = 0; i < n; ++i) {
+            if (a[i].secondary >= 0) {
+                a[i].secondary_all = z[a[i].secondary];
+                if (a[i].is_alt) a[i].secondary = INT_MAX_;
+            } else a[i].secondary_all = -1;
+        }
+        if (n_pri > 0) {
+            for (i = 0; i < n_pri; ++i) { a[i].sub = 0; a[i].secondary = -1; }
+            mark_primary_core(opt, n_pri, a, z);
+        }
+    } else {
+        for (i = 0; i < n; ++i) a[i].secondary_all = a[i].secondary;
+    }
+    return n_pri;
+}
+
+DEV void reorder_primary5(int T, int n, AlnReg* a)
+{
+    int k, n_pri = 0, left_st = INT_MAX_, left_k = -1;
+    for (k = 0; k < n; ++k)
+        if (a[k].secondary < 0 && !a[k].is_alt && a[k].score >= T) ++n_pri;
+    if (n_pri <= 1) return;
+    for (k = 0; k < n; ++k) {
+        if (a[k].secondary >= 0 || a[k].is_alt || a[k].score < T) continue;
+        if (a[k].qb < left_st) { left_st = a[k].qb; left_k = k; }
+    }
+    if (left_k == 0) return;
+    AlnReg t = a[0]; a[0] = a[left_k]; a[left_k] = t;
+    for (k = 1; k < n; ++k) {
+        AlnReg* p = &a[k];
+        if (p->secondary == 0) p->secondary = left_k;
+        else if (p->secondary == left_k) p->secondary = 0;
+        if (p->secondary_all == 0) p->secondary_all = left_k;
+        else if (p->secondary_all == left_k) p->secondary_all = 0;
+    }
+}
+
+// ------------------------------------------------------------------ XA (a17, mem_gen_alt)
+DEV int get_pri_idx(double XA_drop_ratio, const AlnReg* a, int i)
+{
+    int k = a[i].secondary_all;
+    if (k >= 0 && a[i].score >= a[k].score * XA_drop_ratio) return k;
+    return -1;
+}
+
+// cnt[] / has_alt[] of mem_gen_alt; returns tot
+DEV int xa_prepare(const MemOpt& opt, int n, const AlnReg* a, int32_t* cnt, int32_t* has_alt)
+{
+    int tot = 0;
+    for (int i = 0; i < n; ++i) { cnt[i] = 0; has_alt[i] = 0; }
+    for (int i = 0; i < n; ++i) {
+        int r = get_pri_idx(opt.XA_drop_ratio, a, i);
+        if (r >= 0) { ++cnt[r]; ++tot; if (a[i].is_alt) has_alt[r] = 1; }
+    }
+    return tot;
+}
+
+// append the XA string of primary k to ob; returns its length
+DEV int xa_emit(const DevIndex& ix, const MemOpt& opt, PostScratch& S, OutBuf& ob, int l_query, const uint8_t* query,
+                int n, const AlnReg* a, const int32_t* cnt, const int32_t* has_alt, int k)
+{
+    int start = ob.len;
+    if (cnt[k] == 0) return 0;
+    if (cnt[k] > opt.max_XA_hits_alt || (!has_alt[k] && cnt[k] > opt.max_XA_hits)) return 0;
+    for (int i = 0; i < n; ++i) {
+        if (get_pri_idx(opt.XA_drop_ratio, a, i) != k) continue;
+        AlnRec t = reg2aln(ix, opt, S, l_query, query, &a[i]);
+        const char* nm = ix.names + ix.ann_name_off[t.rid];
+        int nl = ix.ann_name_off[t.rid + 1] - ix.ann_name_off[t.rid] - 1;
+        for (int j = 0; j < nl; ++j) ob.putc(nm[j]);
+        ob.putc(','); ob.putc("+-"[t.is_rev]); ob.putl((long)(t.pos + 1));
+        ob.putc(',');
+        for (int j = 0; j < t.n_cigar; ++j) { ob.putl((long)(t.cigar[j] >> 4)); ob.putc("MIDSHN"[t.cigar[j] & 0xf]); }
+        ob.putc(','); ob.putl(t.NM);
+        ob.putc(';');
+    }
+    return ob.len - start;
+}
+
+// ------------------------------------------------------------------ record writer (a18)
+// upstream mem_aln2sam's flag prologue followed by the reference's fmt_BAMish (jnibwa.c:43-97).
+// xa_* describe how to produce the XA string of this record (k < 0: none).
+DEV void aln2out(const DevIndex& ix, const MemOpt& opt, PostScratch& S, OutBuf& ob, int n_recs, int which, AlnRec p, const MateInfo* m_,
+                 int l_query, const uint8_t* query, int n_regs, const AlnReg* regs, const int32_t* cnt, const int32_t* has_alt, int xa_k)
+{
+    MateInfo mt; const bool has_m = m_ != 0;
+    if (has_m) mt = *m_;
+    p.flag |= has_m ? 0x1 : 0;
+    p.flag |= p.rid < 0 ? 0x4 : 0;
+    p.flag |= has_m && mt.rid < 0 ? 0x8 : 0;
+    if (p.rid < 0 && has_m && mt.rid >= 0) { p.rid = mt.rid; p.pos = mt.pos; p.is_rev = mt.is_rev; p.n_cigar = 0; p.ref_len = 0; }
+    if (has_m && mt.rid < 0 && p.rid >= 0) { mt.rid = p.rid; mt.pos = p.pos; mt.is_rev = p.is_rev; mt.ref_len = 0; }
+    p.flag |= p.is_rev ? 0x10 : 0;
+    p.flag |= has_m && mt.is_rev ? 0x20 : 0;
+    if (!which) ob.put32(n_recs);
+    int32_t flag_mapQ = p.flag;
+    if (p.flag & 0x10000) flag_mapQ |= 0x100;
+    flag_mapQ = (int32_t)((uint32_t)flag_mapQ << 16) | (p.mapq & 0xff);
+    ob.put32(flag_mapQ);
+    if (!(p.flag & 0x4)) {
+        ob.put32(p.rid);
+        ob.put32((int32_t)p.pos);
+        ob.put32(p.NM);
+        ob.put32(p.score);
+        ob.put32(p.sub);
+        ob.put32(p.n_cigar);
+        for (int i = 0; i < p.n_cigar; ++i) {
+            uint32_t lenOp = p.cigar[i];
+            if ((lenOp & 0xf) > 2) ++lenOp;             // MIDSH -> BAM MIDNSH
+            ob.put32((int32_t)lenOp);
+        }
+        int nMD = p.n_cigar ? p.l_md : 0;
+        ob.put32(nMD);
+        for (int i = 0; i < nMD; ++i) ob.putc(p.md[i]);
+        ob.pad4();
+        int at = ob.len;
+        ob.put32(0);                                    // nXA, patched below
+        if (xa_k >= 0 && cnt) {
+            int nXA = xa_emit(ix, opt, S, ob, l_query, query, n_regs, regs, cnt, has_alt, xa_k);
+            ob.pad4();
+            if (!ob.ovf) *(int32_t*)(ob.p + at) = nXA;
+        }
+    }
+    if ((p.flag & 0x9) == 1) {
+        ob.put32(mt.rid);
+        ob.put32((int32_t)mt.pos);
+        if ((p.flag & 0x4) || p.rid != mt.rid) ob.put32(0);
+        else {                                          // jnibwa.c:82-95
+            long p0 = (long)p.pos, m0 = (long)mt.pos;
+            if (p.is_rev) p0 += p.ref_len - 1;
+            if (mt.is_rev) m0 += mt.ref_len - 1;
+            ob.put32((int32_t)(m0 - p0 + (p0 > m0 ? -1 : p0 < m0 ? 1 : 0)));
+        }
+    }
+}
+
+// mem_reg2sam: select the records of one read and write them
+DEV void reg2sam(const DevIndex& ix, const MemOpt& opt, PostScratch& S, OutBuf& ob, int l_query, const uint8_t* query,
+                 int n, AlnReg* a, int32_t* zbuf, int extra_flag, const MateInfo* m)
+{
+    int32_t *cnt = 0, *has_alt = 0;
+    if (!(opt.flag & MEM_F_ALL) && n > 0) {
+        cnt = zbuf; has_alt = zbuf + n;
+        if (xa_prepare(opt, n, a, cnt, has_alt) == 0) cnt = has_alt = 0;
+    }
+    int n_aa = 0;
+    for (int k = 0; k < n; ++k) {                       // selection pass (conditions use regions only)
+        const AlnReg* p = &a[k];
+        if (p->score < opt.T) continue;
+        if (p->secondary >= 0 && (p->is_alt || !(opt.flag & MEM_F_ALL))) continue;
+        if (p->secondary >= 0 && p->secondary < INT_MAX_ && (float)p->score < (float)a[p->secondary].score * opt.drop_ratio) continue;
+        ++n_aa;
+    }
+    if (n_aa == 0) {
+        AlnRec t = reg2aln(ix, opt, S, l_query, query, 0);
+        t.flag |= extra_flag;
+        aln2out(ix, opt, S, ob, 1, 0, t, m, l_query, query, n, a, 0, 0, -1);
+        return;
+    }
+    int l = 0, mapq0 = 0;
+    for (int k = 0; k < n; ++k) {
+        const AlnReg* p = &a[k];
+        if (p->score < opt.T) continue;
+        if (p->secondary >= 0 && (p->is_alt || !(opt.flag & MEM_F_ALL))) continue;
+        if (p->secondary >= 0 && p->secondary < INT_MAX_ && (float)p->score < (float)a[p->secondary].score * opt.drop_ratio) continue;
+        AlnRec q = reg2aln(ix, opt, S, l_query, query, p);
+        q.flag |= extra_flag;
+        if (p->secondary >= 0) q.sub = -1;
+        if (l && p->secondary < 0) q.flag |= (opt.flag & MEM_F_NO_MULTI) ? 0x10000 : 0x800;
+        if (l && !p->is_alt && q.mapq > mapq0) q.mapq = mapq0;
+        if (l == 0) mapq0 = q.mapq;
+        // the record's own CIGAR/MD must be written before XA reuses the scratch: aln2out does that in order
+        aln2out(ix, opt, S, ob, n_aa, l, q, m, l_query, query, n, a, cnt, has_alt, cnt ? k : -1);
+        ++l;
+    }
+}

@@ -1,0 +1,89 @@
+/*
+ * bwamem_hip.h -- C ABI of the MI355X-native BWA-MEM library (libbwamem_hip.so).
+ *
+ * The first block is the drop-in boundary: the same JNI-free entry points the reference's
+ * JNI glue binds (reference: src/main/c/jnibwa.h:11-16, defined in src/main/c/jnibwa.c), with
+ * identical argument meaning, ownership and error behaviour.  A maintainer of
+ * broadinstitute/gatk-bwamem-jni links org_broadinstitute_hellbender_utils_bwa_BwaMemIndex.c
+ * and init.c against this library instead of jnibwa.o + libbwa.a.
+ * Handles are opaque; plain pointers and sizes only.
+ */
+#ifndef BWAMEM_HIP_H_
+#define BWAMEM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bwaidx_s bwaidx_t;      /* opaque; the jlong handle of BwaMemIndex.java:83 */
+typedef struct mem_opt_s mem_opt_t;    /* 168 bytes, offsets pinned by BwaMemAligner.java:46-138 */
+typedef struct mem_pestat_s mem_pestat_t; /* {int low, high, failed; double avg, std;}, 32 bytes x 4 orientations */
+
+/* replaces bwa_idx_build() as called from ...BwaMemIndex.c:59 (declared, never defined, at jnibwa.h:11).
+ * algo: "auto", "is", "rb2" select nothing here (one builder); any other name returns -1.  0 = ok. */
+int jnibwa_createReferenceIndex(const char* refFileName, const char* indexPrefix, const char* algoName);
+
+/* jnibwa.c:126-152: <prefix>.{amb,ann,bwt,pac,sa}[,alt] -> one contiguous image file.  0 ok, 2 I/O error. */
+int jnibwa_createIndexFile(const char* refName, const char* imgName);
+
+/* jnibwa.c:154-165: takes ownership of fd; mmaps the image read-only, uploads bwt/occ, SA and pac
+ * to HBM.  Returns 0 on failure (Java then throws CouldNotReadImageException, BwaMemIndex.java:334). */
+bwaidx_t* jnibwa_openIndex(int fd);
+
+/* jnibwa.c:167-172 */
+int jnibwa_destroyIndex(bwaidx_t* pIdx);
+
+/* jnibwa.c:174-195: int32 n, then (int32 len, bytes) per contig; free with jnibwa_free */
+void* jnibwa_getRefContigNames(bwaidx_t* pIdx, size_t* pBufSize);
+
+/* jnibwa.c:197-235: pSeq = uint32 nSeqs + nSeqs NUL-terminated base strings (bases are overwritten
+ * with 0..4 codes, as upstream does); peStats = mem_pestat_t[4] or NULL (infer).  Returns a malloc'ed
+ * int32 stream in the layout of ...BwaMemIndex.c:115-141, or NULL on any device error. */
+void* jnibwa_createAlignments(bwaidx_t* pIdx, mem_opt_t* pOpts, mem_pestat_t* peStats, char* pSeq, size_t* pBufSize);
+
+/* mem_opt_init() as wrapped at ...BwaMemIndex.c:89-92; free with jnibwa_free */
+mem_opt_t* jnibwa_createDefaultOptions(void);
+
+/* the one allocator behind destroyByteBuffer (...BwaMemIndex.c:157-160) */
+void jnibwa_free(void* p);
+
+/* ...BwaMemIndex.c:163-165 */
+const char* jnibwa_getVersion(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Additive device-level entry points (bench, multi-GPU drivers).  Not part of the reference ABI. */
+
+int bwamem_hip_set_device(int device);        /* device used by subsequently opened indexes */
+int bwamem_hip_device_count(void);
+
+typedef struct bwamem_batch_s bwamem_batch_t; /* a request resident in HBM */
+
+/* upload a request buffer (same wire format as pSeq above); the host buffer is left untouched */
+bwamem_batch_t* bwamem_hip_batch_upload(bwaidx_t* idx, const char* pSeq, size_t nBytes);
+/* run the whole hot path; results stay in HBM.  read_id0 = index of the first read within the
+ * logical call (shards of one call must carry their global base index).  0 = ok. */
+int bwamem_hip_batch_align(bwaidx_t* idx, const mem_opt_t* opt, const mem_pestat_t* pes, bwamem_batch_t* b, int64_t read_id0);
+size_t bwamem_hip_batch_result_bytes(const bwamem_batch_t* b);
+int bwamem_hip_batch_download(bwamem_batch_t* b, void* dst);
+void bwamem_hip_batch_free(bwamem_batch_t* b);
+
+typedef struct {
+    /* algorithmic counters */
+    uint64_t n_reads, n_ext, n_lf, n_sa, n_dp_cells;
+    /* accumulated device time per kernel, ms, and launch counts (HIP events on the launch stream) */
+    double ms_encode, ms_seed, ms_sa, ms_chain, ms_extend, ms_post, ms_final, ms_pack, ms_other;
+    uint64_t n_launch_seed, n_launch_sa, n_launch_extend;
+    uint64_t n_tiles, n_retries;
+} bwamem_stats_t;
+
+void bwamem_hip_stats_enable(int on);          /* per-kernel HIP-event timing (off by default) */
+void bwamem_hip_stats_reset(void);
+void bwamem_hip_stats_get(bwamem_stats_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,101 @@
+// tests/emu/emu_runtime.cpp -- TEST INFRASTRUCTURE ONLY: fiber scheduler behind hip/hip_runtime.h.
+#include <hip/hip_runtime.h>
+#include <ucontext.h>
+#include <sys/mman.h>
+#include <stdio.h>
+#include <vector>
+
+dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace emu {
+
+static const size_t STACK = 512 * 1024;
+
+struct Fiber { ucontext_t ctx; char* stack; bool done; unsigned tid; };
+struct WaveState { int arrive = 0; unsigned gen = 0; int alive = 0; uint64_t alive_mask = 0; uint64_t slots[64]; };
+
+static ucontext_t g_sched;
+static std::vector<Fiber> g_fibers;
+static std::vector<WaveState> g_waves;
+static int g_block_arrive = 0, g_block_alive = 0; static unsigned g_block_gen = 0;
+static Fiber* g_cur = nullptr;
+static const std::function<void()>* g_body = nullptr;
+static std::vector<char> g_dyn;
+static std::vector<char*> g_stack_pool;
+
+void* dyn_smem() { return g_dyn.data(); }
+uint64_t* wave_slots() { return g_waves[g_cur->tid >> 6].slots; }
+uint64_t wave_alive_mask() { return g_waves[g_cur->tid >> 6].alive_mask; }
+
+static void yield() { Fiber* f = g_cur; swapcontext(&f->ctx, &g_sched); threadIdx.x = f->tid; }
+
+void sync_wave()
+{
+    WaveState& w = g_waves[g_cur->tid >> 6];
+    unsigned my = w.gen;
+    if (++w.arrive == w.alive) { w.arrive = 0; ++w.gen; return; }
+    while (w.gen == my) yield();
+}
+
+void sync_block()
+{
+    unsigned my = g_block_gen;
+    if (++g_block_arrive == g_block_alive) { g_block_arrive = 0; ++g_block_gen; return; }
+    while (g_block_gen == my) yield();
+}
+
+static void trampoline()
+{
+    (*g_body)();
+    Fiber* f = g_cur;
+    f->done = true;
+    WaveState& w = g_waves[f->tid >> 6];
+    --w.alive; w.alive_mask &= ~(1ull << (f->tid & 63));
+    if (w.alive > 0 && w.arrive == w.alive) { w.arrive = 0; ++w.gen; }
+    --g_block_alive;
+    if (g_block_alive > 0 && g_block_arrive == g_block_alive) { g_block_arrive = 0; ++g_block_gen; }
+    swapcontext(&f->ctx, &g_sched);
+}
+
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body)
+{
+    const unsigned nt = block.x;
+    gridDim = grid; blockDim = block;
+    g_body = &body;
+    while (g_stack_pool.size() < nt) {
+        char* s = (char*)mmap(0, STACK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        g_stack_pool.push_back(s);
+    }
+    g_fibers.resize(nt);
+    for (unsigned b = 0; b < grid.x; ++b) {
+        blockIdx = dim3(b);
+        g_dyn.assign(shmem + 64, (char)0xCD);
+        g_waves.assign((nt + 63) / 64, WaveState());
+        g_block_arrive = 0; g_block_alive = (int)nt; g_block_gen = 0;
+        for (unsigned t = 0; t < nt; ++t) {
+            Fiber& f = g_fibers[t];
+            f.stack = g_stack_pool[t]; f.done = false; f.tid = t;
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = 0;
+            makecontext(&f.ctx, (void (*)())trampoline, 0);
+            WaveState& w = g_waves[t >> 6];
+            ++w.alive; w.alive_mask |= 1ull << (t & 63);
+        }
+        unsigned remaining = nt;
+        while (remaining) {
+            unsigned progressed = 0;
+            for (unsigned t = 0; t < nt; ++t) {
+                Fiber& f = g_fibers[t];
+                if (f.done) continue;
+                g_cur = &f; threadIdx = dim3(t);
+                swapcontext(&g_sched, &f.ctx);
+                if (f.done) { --remaining; }
+                ++progressed;
+            }
+            if (!progressed) break;
+        }
+    }
+    g_body = nullptr;
+}
+
+} // namespace emu
