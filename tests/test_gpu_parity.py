@@ -1,0 +1,145 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the
+committed golden vectors.  Bit-exact is the bar: all arithmetic on the path is integer / byte /
+index work (the few float/double decisions must round identically)."""
+import json
+import os
+import sys
+
+import pytest
+
+import bwalib as B
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, B.PKG)
+
+
+@pytest.fixture(scope="module")
+def bwamem():
+    import bwamem
+    return bwamem
+
+
+@pytest.fixture(scope="module")
+def rota_index(bwamem, workdir):
+    img = os.path.join(workdir, "rota_hip.img")
+    bwamem.BwaMemIndex.createIndexImageFromIndexFiles(os.path.join(B.GOLDEN, "rotavirus", "ref.fa"), img)
+    index = bwamem.BwaMemIndex(img)
+    yield index
+    index.close()
+
+
+def check(alignment, refStart, refEnd, seqStart, seqEnd, cigar, nMismatches, samFlag):
+    # BwaMemIndexTest.testAlignment, :129-140
+    assert alignment.getRefStart() == refStart
+    assert alignment.getRefEnd() == refEnd
+    assert alignment.getSeqStart() == seqStart
+    assert alignment.getSeqEnd() == seqEnd
+    assert alignment.getCigar() == cigar
+    assert alignment.getNMismatches() == nMismatches
+    assert alignment.getRefId() == 0
+    assert alignment.getSamFlag() == samFlag
+
+
+def test_opts_size(bwamem, rota_index):           # BwaMemIndexTest.testOptsSize
+    aligner = bwamem.BwaMemAligner(rota_index)
+    assert aligner.getOptsSize() == aligner.getExpectedOptsSize() == 168
+
+
+def test_simple(bwamem, rota_index):              # BwaMemIndexTest.testSimple
+    aligner = bwamem.BwaMemAligner(rota_index)
+    alignments = aligner.alignSeqs(["GGCTTTTAATGCTTTTCAGTGGTTGCTGCTCAAGATGGAGTCTACTCAGCAGATGGTAAGCTCTATTATT"])
+    assert len(alignments) == 1 and len(alignments[0]) == 1
+    check(alignments[0][0], 0, 70, 0, 70, "70M", 0, 0)
+
+
+def test_multi(bwamem, rota_index):               # BwaMemIndexTest.testMulti
+    aligner = bwamem.BwaMemAligner(rota_index)
+    seqs = ["GGCTTTTAATGCTTTTCAGTGCTAGGTGCTCAAGATGGAGTCTACTCAGCAGATGGTAAGCTCTATTATT",
+            "AATAATAGAGCTTACCATCTGCTGAGTAGACTCCATCTTGAGCAGCAACCACTGAAAAGCATTAAAAGCC",
+            "AATACTTCTTTTGAAGCTGCAGTTGTTGCTGCCTTCAACATTAGAATTAATGGGTATTCAATATGATT"]
+    alignments = aligner.alignSeqs(seqs)
+    assert [len(a) for a in alignments] == [1, 1, 1]
+    check(alignments[0][0], 0, 70, 0, 70, "70M", 3, 0)
+    check(alignments[1][0], 0, 70, 0, 70, "70M", 0, 0x10)
+    check(alignments[2][0], 70, 140, 0, 68, "32M2D36M", 2, 0)
+
+
+def test_golden_vectors(bwamem, rota_index):
+    """every SE vector of tests/golden/reference_tests.json (from BwaMemIndexTest.java:45-82)"""
+    gold = json.load(open(os.path.join(B.GOLDEN, "reference_tests.json")))
+    aligner = bwamem.BwaMemAligner(rota_index)
+    for case in gold["single_end"]:
+        alns = aligner.alignSeqs(case["reads"])
+        for got, want in zip(alns, case["expect"]):
+            assert len(got) == 1
+            check(got[0], want["refStart"], want["refEnd"], want["seqStart"], want["seqEnd"], want["cigar"], want["NM"], want["flag"])
+
+
+def _parity(hip, orc, img, reads, **optkw):
+    h, ho = hip.open_index(img), orc.open_index(img)
+    try:
+        opts = B.set_opt(hip.default_options(), **optkw)
+        req = B.pack_request(reads)
+        got = hip.align_raw(h, opts, req)
+        want = orc.align_raw(ho, opts, req)
+        assert got is not None
+        if got != want:
+            sa, sb = B.split_response(got, len(reads)), B.split_response(want, len(reads))
+            bad = [i for i in range(len(reads)) if sa[i] != sb[i]]
+            msg = "%d/%d reads differ; first: read %d %r\n  hip    %r\n  oracle %r" % (
+                len(bad), len(reads), bad[0], reads[bad[0]], B.decode_response(sa[bad[0]], 1), B.decode_response(sb[bad[0]], 1))
+            pytest.fail(msg)
+        return got
+    finally:
+        hip.destroy_index(h); orc.destroy_index(ho)
+
+
+def test_parity_rotavirus(hip_lib, oracle, rota_img):
+    seqs = [("rotavirus", open(os.path.join(B.GOLDEN, "rotavirus", "ref.fa")).read().split("\n", 1)[1].replace("\n", "").encode())]
+    reads = B.simulate_reads(seqs, 400, length=70, seed=5, sub=0.03, indel=0.004)
+    _parity(hip_lib, oracle, rota_img, reads)
+
+
+def test_parity_small_genome(hip_lib, oracle, small_genome):
+    seqs, img = small_genome
+    reads = B.simulate_reads(seqs, 3000, length=150, seed=1, sub=0.02, indel=0.003, n_rate=0.002, random_frac=0.02)
+    _parity(hip_lib, oracle, img, reads)
+
+
+def test_parity_ragged_and_edge_cases(hip_lib, oracle, small_genome):
+    seqs, img = small_genome
+    reads = B.simulate_reads(seqs, 300, length=60, seed=2) + B.simulate_reads(seqs, 300, length=251, seed=3, sub=0.05, indel=0.01)
+    reads += [b"", b"A", b"ACGT" * 4, b"N" * 150, b"ACGTN" * 30, b"acgtacgtacgtacgtacgtacgtacgt", seqs[0][1][:18], seqs[0][1][:19], seqs[0][1][100:120],
+              seqs[1][1][-150:], B.revcomp(seqs[1][1][:150]), seqs[0][1][500:575] + seqs[2][1][900:975]]
+    _parity(hip_lib, oracle, img, reads)
+
+
+def test_empty_request(hip_lib, oracle, rota_img):
+    h = hip_lib.open_index(rota_img)
+    got = hip_lib.align_raw(h, hip_lib.default_options(), B.pack_request([]))
+    hip_lib.destroy_index(h)
+    assert got == b""
+
+
+def test_parity_options(hip_lib, oracle, small_genome):
+    seqs, img = small_genome
+    reads = B.simulate_reads(seqs, 500, length=120, seed=9, sub=0.03, indel=0.005)
+    _parity(hip_lib, oracle, img, reads, flag=B.MEM_F_ALL)
+    _parity(hip_lib, oracle, img, reads, o_del=16, o_ins=16, b=9, pen_clip5=5, pen_clip3=5)     # setIntraCtgOptions
+    _parity(hip_lib, oracle, img, reads, w=10, zdrop=20, T=40, min_seed_len=15, max_occ=20)
+    _parity(hip_lib, oracle, img, reads, flag=B.MEM_F_NO_MULTI | B.MEM_F_PRIMARY5, XA_drop_ratio=0.5, max_XA_hits=2)
+
+
+def test_multi_tile_equals_single_tile(hip_lib, oracle, small_genome, monkeypatch):
+    seqs, img = small_genome
+    reads = B.simulate_reads(seqs, 1000, length=100, seed=21)
+    whole = _parity(hip_lib, oracle, img, reads)
+    monkeypatch.setenv("BWAMEM_HIP_TILE", "97")
+    tiled = _parity(hip_lib, oracle, img, reads)
+    assert whole == tiled
+
+
+def test_parity_medium_genome(hip_lib, oracle, medium_genome):
+    seqs, img = medium_genome
+    reads = B.simulate_reads(seqs, 20000, length=150, seed=42)
+    _parity(hip_lib, oracle, img, reads)
