@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""bench.py -- reads aligned per second on MI355X for BASELINE.json's headline workload.
+
+Workload (config.workload): configs[1] of BASELINE.json -- 10 M x 150 bp single-end synthetic
+reads vs a GRCh38-scale reference, full index resident in HBM.  GRCh38 itself is not available
+offline, so the reference is the seeded synthetic genome of SURVEY.md section 8(d): 24 contigs,
+3.1e9 bp, i.i.d. ACGT with 5 % of the bases overwritten by diverged copies of 300 bp - 6 kb
+segments; it is indexed on the device by gatk-bwamem-jni_amd/index_build_gpu.py.
+
+A "step" is one pass of the whole hot path (encode -> SMEM seeding -> SA lookup -> chaining ->
+banded extension -> region post-processing -> records -> packed response) over the batch, with
+the request already resident in HBM and the response left in HBM.  One process per GPU; reads
+shard across ranks with no collective (weak scaling: every rank aligns --reads reads); the only
+torch.distributed traffic is the barrier and the max-over-ranks of the elapsed time.
+"""
+import argparse
+import ctypes
+import json
+import os
+import struct
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "gatk-bwamem-jni_amd")
+sys.path.insert(0, PKG)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("n_reads", "n_ext", "n_lf", "n_sa", "n_dp_cells")] + \
+               [(n, ctypes.c_double) for n in ("ms_encode", "ms_seed", "ms_sa", "ms_chain", "ms_extend", "ms_post", "ms_final", "ms_pack", "ms_other")] + \
+               [(n, ctypes.c_uint64) for n in ("n_launch_seed", "n_launch_sa", "n_launch_extend", "n_tiles", "n_retries")]
+
+
+def load_lib():
+    path = os.path.join(PKG, "libbwamem_hip.so")
+    if not os.path.exists(path):
+        raise SystemExit("libbwamem_hip.so is missing (run __graft_entry__.build()); there is no fallback path")
+    lib = ctypes.CDLL(path)
+    lib.jnibwa_openIndex.restype = ctypes.c_void_p
+    lib.jnibwa_openIndex.argtypes = [ctypes.c_int]
+    lib.jnibwa_destroyIndex.argtypes = [ctypes.c_void_p]
+    lib.jnibwa_createDefaultOptions.restype = ctypes.c_void_p
+    lib.jnibwa_createAlignments.restype = ctypes.c_void_p
+    lib.jnibwa_createAlignments.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    lib.jnibwa_free.argtypes = [ctypes.c_void_p]
+    lib.bwamem_hip_set_device.argtypes = [ctypes.c_int]
+    lib.bwamem_hip_batch_wrap_device.restype = ctypes.c_void_p
+    lib.bwamem_hip_batch_wrap_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p]
+    lib.bwamem_hip_batch_align.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    lib.bwamem_hip_batch_result_bytes.restype = ctypes.c_size_t
+    lib.bwamem_hip_batch_result_bytes.argtypes = [ctypes.c_void_p]
+    lib.bwamem_hip_batch_free.argtypes = [ctypes.c_void_p]
+    lib.bwamem_hip_stats_get.argtypes = [ctypes.POINTER(Stats)]
+    return lib
+
+
+def synth_genome(torch, dev, total_bp, n_contigs, seed):
+    """i.i.d. ACGT + 5 % diverged repeat copies; returns (codes uint8, [(name, len)])"""
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    w = torch.rand(n_contigs, generator=g, device=dev) + 0.5
+    lens = (w / w.sum() * total_bp).long()
+    lens[-1] += total_bp - int(lens.sum())
+    codes = torch.randint(0, 4, (total_bp,), dtype=torch.uint8, generator=g, device=dev)
+    n_rep = int(0.05 * total_bp)
+    hg = torch.Generator(); hg.manual_seed(seed + 1)
+    done = 0
+    while done < n_rep and total_bp > 20000:
+        l = int(torch.randint(300, 6000, (1,), generator=hg))
+        src = int(torch.randint(0, total_bp - l, (1,), generator=hg)); dst = int(torch.randint(0, total_bp - l, (1,), generator=hg))
+        seg = codes[src:src + l].clone()
+        mut = torch.rand(l, generator=g, device=dev) < 0.03
+        seg = torch.where(mut, (seg + torch.randint(1, 4, (l,), dtype=torch.uint8, generator=g, device=dev)) % 4, seg)
+        if int(torch.randint(0, 2, (1,), generator=hg)):
+            seg = torch.flip(3 - seg, [0])
+        codes[dst:dst + l] = seg
+        done += l
+    contigs = [("chr%d" % (i + 1), int(lens[i])) for i in range(n_contigs)]
+    return codes, contigs
+
+
+def synth_reads(torch, dev, codes, contigs, n, length, seed):
+    """uniform position/strand, 1 % substitutions, 0.02 %/base indels (one event per affected
+    read, geometric length), 0.1 % N, 0.5 % random reads.  Returns the request payload (n x (length+1) ASCII, NUL-terminated)."""
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    total = codes.numel()
+    slack = 40
+    # start positions that keep length+slack bases inside one contig
+    bounds = torch.tensor([0] + [l for _, l in contigs], device=dev).cumsum(0)
+    pos = (torch.rand(n, generator=g, device=dev, dtype=torch.float64) * (total - length - slack)).long()
+    ci = torch.searchsorted(bounds, pos, right=True) - 1
+    end_ok = pos + length + slack <= bounds[ci + 1]
+    pos = torch.where(end_ok, pos, torch.clamp(bounds[ci + 1] - length - slack, min=0))
+    col = torch.arange(length, device=dev)
+    # one indel event for a fraction of reads
+    has = torch.rand(n, generator=g, device=dev) < (0.0002 * length)
+    is_del = torch.rand(n, generator=g, device=dev) < 0.5
+    ev = (torch.rand(n, generator=g, device=dev) * (length - 20)).long() + 10
+    k = torch.clamp(torch.log(torch.rand(n, generator=g, device=dev)).div(-0.6931).floor().long() + 1, max=slack - 1)
+    k = torch.where(has, k, torch.zeros_like(k))
+    shift = torch.where(is_del, k, -k)                                   # deletion reads further right, insertion shifts left
+    after = col[None, :] >= torch.where(is_del, ev, ev + k)[:, None]
+    src = pos[:, None] + col[None, :] + torch.where(after, shift[:, None], torch.zeros_like(shift)[:, None])
+    b = codes[src]
+    ins_zone = (~is_del)[:, None] & (col[None, :] >= ev[:, None]) & (col[None, :] < (ev + k)[:, None])
+    rnd = torch.randint(0, 4, (n, length), dtype=torch.uint8, generator=g, device=dev)
+    b = torch.where(ins_zone, rnd, b)
+    sub = torch.rand(n, length, generator=g, device=dev) < 0.01
+    b = torch.where(sub, (b + 1 + rnd % 3) % 4, b)
+    rc = torch.rand(n, generator=g, device=dev) < 0.5
+    b = torch.where(rc[:, None], torch.flip(3 - b, [1]), b)
+    junk = torch.rand(n, generator=g, device=dev) < 0.005
+    b = torch.where(junk[:, None], rnd, b)
+    asc = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[b.long()]
+    nmask = torch.rand(n, length, generator=g, device=dev) < 0.001
+    asc = torch.where(nmask, torch.full_like(asc, ord("N")), asc)
+    payload = torch.zeros((n, length + 1), dtype=torch.uint8, device=dev)
+    payload[:, :length] = asc
+    return payload
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--genome-bp", type=int, default=3_100_000_000)
+    ap.add_argument("--contigs", type=int, default=24)
+    ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads timed through the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--image", default=None, help="use an existing .img (e.g. GATK's Homo_sapiens_assembly38.fasta.img) instead of the synthetic genome")
+    args = ap.parse_args()
+
+    import torch
+    import numpy as np
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    lib = load_lib()
+    lib.bwamem_hip_set_device(local)
+
+    # ---- reference + index (not timed)
+    t0 = time.time()
+    if args.image:
+        img = args.image
+        raise SystemExit("--image needs the packed reference to sample reads from; not wired yet")
+    codes, contigs = synth_genome(torch, dev, args.genome_bp, args.contigs, 0x5EED)
+    import index_build_gpu as G
+    pieces = G.build_pieces(codes)
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    img = os.path.join(tmpdir, "bwamem_hip_bench_%d_%d.img" % (os.getpid(), rank))
+    G.write_image(img, pieces, contigs)
+    del pieces
+    torch.cuda.empty_cache()
+    t_index = time.time() - t0
+    idx = lib.jnibwa_openIndex(os.open(img, os.O_RDONLY))
+    if not idx:
+        raise SystemExit("openIndex failed")
+
+    # ---- request resident in HBM (not timed)
+    L, R = args.read_len, args.reads
+    payload = synth_reads(torch, dev, codes, contigs, R, L, 42 + rank)
+    del codes
+    torch.cuda.empty_cache()
+    h_off = (np.arange(R + 1, dtype=np.int64) * (L + 1))
+    torch.cuda.synchronize()
+    batch = lib.bwamem_hip_batch_wrap_device(idx, payload.data_ptr(), R * (L + 1), R, h_off.ctypes.data)
+    if not batch:
+        raise SystemExit("batch_wrap_device failed")
+    p = lib.jnibwa_createDefaultOptions()
+    opts = ctypes.create_string_buffer(ctypes.string_at(p, 168), 168)
+    lib.jnibwa_free(p)
+
+    def step():
+        if lib.bwamem_hip_batch_align(idx, opts, None, batch, rank * R) != 0:
+            raise SystemExit("align failed")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    lib.bwamem_hip_stats_enable(1)
+    lib.bwamem_hip_stats_reset()
+    barrier()
+    t1 = time.time()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.time() - t1
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = Stats(); lib.bwamem_hip_stats_get(ctypes.byref(st))
+    lib.bwamem_hip_stats_enable(0)
+    result_bytes = lib.bwamem_hip_batch_result_bytes(batch)
+
+    out = None
+    if rank == 0:
+        value = world * R * args.steps / elapsed
+        kern = dict(encode=st.ms_encode, seed=st.ms_seed, sa=st.ms_sa, chain=st.ms_chain, extend=st.ms_extend, post=st.ms_post, final=st.ms_final, pack=st.ms_pack, other=st.ms_other)
+        # roofline of the occurrence-table gather kernel (k_seed): 2 x 64-byte occ lines per interval extension
+        n_launch = max(1, st.n_launch_seed)
+        alg_bytes = 128.0 * st.n_ext / n_launch
+        avg_s = st.ms_seed * 1e-3 / n_launch
+        achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        out = {
+            "metric": "150bp reads aligned/sec vs GRCh38-scale reference (1/2/4/8 MI355X)", "value": value, "unit": "reads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32/int64", "data": "synthetic",
+            "config": {"workload": "%d x %dbp single-end synthetic reads per GPU vs synthetic GRCh38-scale genome (%d bp, %d contigs, 5%% diverged repeats), full index in HBM" % (R, L, args.genome_bp, args.contigs),
+                       "reads_per_gpu": R, "read_len": L, "genome_bp": args.genome_bp, "index_build_s": round(t_index, 1), "response_bytes": result_bytes,
+                       "parallelism": "read-sharded x%d, no collectives" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": int(st.n_launch_seed),
+                         "n_ext_per_read": st.n_ext / max(1, st.n_reads)},
+            "kernel_ms": {k: round(v, 2) for k, v in kern.items()},
+            "counters": {"n_ext": int(st.n_ext), "n_lf": int(st.n_lf), "n_sa": int(st.n_sa), "n_dp_cells": int(st.n_dp_cells), "tiles": int(st.n_tiles), "retries": int(st.n_retries)},
+        }
+
+    # ---- CPU baseline + parity sample (rank 0, N = 1 only)
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        import bwalib as B
+        if not os.path.exists(B.ORACLE_LIB):
+            B.build_oracle()
+        orc = B.oracle_lib()
+        S = min(args.cpu_sample, R)
+        req = struct.pack("<i", S) + payload[:S].cpu().numpy().tobytes()
+        cores = os.cpu_count() or 1
+        ho = orc.open_index(img)
+        oo = B.set_opt(orc.default_options(), n_threads=cores)
+        tc = time.time()
+        want = orc.align_raw(ho, oo, req)
+        tcpu = time.time() - tc
+        orc.destroy_index(ho)
+        rb = ctypes.create_string_buffer(req, len(req)); sz = ctypes.c_size_t()
+        gp = lib.jnibwa_createAlignments(idx, opts, None, rb, ctypes.byref(sz))
+        got = ctypes.string_at(gp, sz.value) if gp else None
+        if gp:
+            lib.jnibwa_free(gp)
+        ident = None
+        if got is not None:
+            a, b = B.split_response(got, S), B.split_response(want, S)
+            ident = sum(1 for x, y in zip(a, b) if x == y) / S
+        out["cpu_baseline"] = {"value": S / tcpu, "unit": "reads/s", "cores": cores, "kind": "port",
+                               "sample": "first %d reads of the same batch through oracle/ (own CPU restatement, not libbwa), %d threads, %.1f s" % (S, cores, tcpu)}
+        out["parity_sample"] = {"reads": S, "frac_identical_records": ident}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    lib.bwamem_hip_batch_free(batch)
+    lib.jnibwa_destroyIndex(idx)
+    try:
+        os.unlink(img)
+    except OSError:
+        pass
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

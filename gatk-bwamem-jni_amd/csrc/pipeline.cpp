@@ -13,6 +13,7 @@
 #include <unistd.h>
 #include <fcntl.h>
 #include <errno.h>
+#include <time.h>
 #include <sys/stat.h>
 #include <sys/mman.h>
 #include <mutex>
@@ -117,11 +118,10 @@ struct bwamem_batch_s {
     bwaidx_s* idx = nullptr;
     uint32_t n_reads = 0;
     size_t n_bytes = 0;
-    DevBuf d_seq, d_off;
+    DevBuf d_raw, d_seq, d_off;     // d_raw: the request as uploaded (ASCII); d_seq: working copy, encoded per call
     std::vector<int64_t> h_off;
     std::vector<TileOut> tiles;
     size_t result_bytes = 0;
-    bool encoded = false;
 };
 
 static const int LOG_TAB_N = 1 << 20;
@@ -208,7 +208,22 @@ static void timed_collect(Workspace& ws)
     }
     ws.timed.clear();
 }
-#define TIMED(ws, id, call) do { timed_begin(ws, id); call; timed_end(ws); } while (0)
+static int g_verbose = -1;
+static bool verbose() { if (g_verbose < 0) { const char* e = getenv("BWAMEM_HIP_VERBOSE"); g_verbose = e && atoi(e) > 0; } return g_verbose > 0; }
+// BWAMEM_HIP_VERBOSE=1: synchronise after every launch and log its wall time (debugging aid only)
+static void verbose_sync(Workspace& ws, const char* what)
+{
+    static double t_last = 0;
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    double t0 = ts.tv_sec + ts.tv_nsec * 1e-9;
+    hipError_t e = hipStreamSynchronize(ws.stream);
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    double t1 = ts.tv_sec + ts.tv_nsec * 1e-9;
+    fprintf(stderr, "[bwamem_hip] %-28s %9.3f ms  (%s)\n", what, (t1 - t0) * 1e3, e == hipSuccess ? "ok" : hipGetErrorString(e));
+    fflush(stderr);
+    t_last = t1; (void)t_last;
+}
+#define TIMED(ws, id, call) do { timed_begin(ws, id); call; timed_end(ws); if (verbose()) verbose_sync(ws, #call); } while (0)
 
 // ------------------------------------------------------------------------------------------ tile loop
 static int64_t post_bytes_per_read(int L, const MemOpt& opt)
@@ -229,10 +244,8 @@ static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, b
     b->tiles.clear(); b->result_bytes = 0;
     if (opt.flag & MEM_F_PE) { fprintf(stderr, "[bwamem_hip] paired-end mode (MEM_F_PE) is not implemented on the device path yet\n"); return false; }
     if (b->n_reads == 0) return true;
-    if (!b->encoded) {
-        TIMED(ws, K_ENCODE, launch_encode(ws.stream, b->d_seq.as<uint8_t>(), (int64_t)b->n_bytes));
-        b->encoded = true;
-    }
+    HIP_OK(hipMemcpyAsync(b->d_seq.p, b->d_raw.p, b->n_bytes, hipMemcpyDeviceToDevice, ws.stream));
+    TIMED(ws, K_ENCODE, launch_encode(ws.stream, b->d_seq.as<uint8_t>(), (int64_t)b->n_bytes));
     const char* env_t = getenv("BWAMEM_HIP_TILE");
     int intv_cap_scale = 1, out_cap = 512;
     int64_t seed_cap_hint = 0;
@@ -442,10 +455,25 @@ bwamem_batch_t* bwamem_hip_batch_upload(bwaidx_t* idx, const char* pSeq, size_t 
     }
     b->h_off[b->n_reads] = p - (pSeq + 4);
     b->n_bytes = (size_t)b->h_off[b->n_reads];
-    bool ok = b->d_seq.ensure(b->n_bytes + 64) && b->d_off.ensure(((size_t)b->n_reads + 1) * 8);
-    ok = ok && hipMemcpy(b->d_seq.p, pSeq + 4, b->n_bytes, hipMemcpyHostToDevice) == hipSuccess
+    bool ok = b->d_raw.ensure(b->n_bytes + 64) && b->d_seq.ensure(b->n_bytes + 64) && b->d_off.ensure(((size_t)b->n_reads + 1) * 8);
+    ok = ok && hipMemcpy(b->d_raw.p, pSeq + 4, b->n_bytes, hipMemcpyHostToDevice) == hipSuccess
             && hipMemcpy(b->d_off.p, b->h_off.data(), ((size_t)b->n_reads + 1) * 8, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { fprintf(stderr, "[bwamem_hip] request upload failed\n"); bwamem_hip_batch_free(b); return 0; }
+    return b;
+}
+
+bwamem_batch_t* bwamem_hip_batch_wrap_device(bwaidx_t* idx, const void* d_payload, size_t nBytes, uint32_t nReads, const int64_t* h_offsets)
+{
+    if (!idx || !d_payload || !h_offsets) return 0;
+    if (hipSetDevice(idx->device) != hipSuccess) return 0;
+    bwamem_batch_s* b = new bwamem_batch_s();
+    b->idx = idx; b->n_reads = nReads; b->n_bytes = nBytes;
+    b->h_off.assign(h_offsets, h_offsets + (size_t)nReads + 1);
+    bool ok = b->h_off[nReads] == (int64_t)nBytes
+        && b->d_raw.ensure(nBytes + 64) && b->d_seq.ensure(nBytes + 64) && b->d_off.ensure(((size_t)nReads + 1) * 8)
+        && hipMemcpy(b->d_raw.p, d_payload, nBytes, hipMemcpyDeviceToDevice) == hipSuccess
+        && hipMemcpy(b->d_off.p, b->h_off.data(), ((size_t)nReads + 1) * 8, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { fprintf(stderr, "[bwamem_hip] batch_wrap_device failed\n"); bwamem_hip_batch_free(b); return 0; }
     return b;
 }
 
@@ -475,7 +503,7 @@ void bwamem_hip_batch_free(bwamem_batch_t* b)
     if (!b) return;
     (void)hipSetDevice(b->idx->device);
     for (TileOut& t : b->tiles) if (t.d) (void)hipFree(t.d);
-    b->d_seq.release(); b->d_off.release();
+    b->d_raw.release(); b->d_seq.release(); b->d_off.release();
     delete b;
 }
 

@@ -39,8 +39,8 @@ int jnibwa_destroyIndex(bwaidx_t* pIdx);
 /* jnibwa.c:174-195: int32 n, then (int32 len, bytes) per contig; free with jnibwa_free */
 void* jnibwa_getRefContigNames(bwaidx_t* pIdx, size_t* pBufSize);
 
-/* jnibwa.c:197-235: pSeq = uint32 nSeqs + nSeqs NUL-terminated base strings (bases are overwritten
- * with 0..4 codes, as upstream does); peStats = mem_pestat_t[4] or NULL (infer).  Returns a malloc'ed
+/* jnibwa.c:197-235: pSeq = uint32 nSeqs + nSeqs NUL-terminated base strings (left untouched here; upstream
+ * overwrites the bases with 0..4 codes, which Java never observes: BwaMemAligner.java:203-210); peStats = mem_pestat_t[4] or NULL (infer).  Returns a malloc'ed
  * int32 stream in the layout of ...BwaMemIndex.c:115-141, or NULL on any device error. */
 void* jnibwa_createAlignments(bwaidx_t* pIdx, mem_opt_t* pOpts, mem_pestat_t* peStats, char* pSeq, size_t* pBufSize);
 
@@ -63,6 +63,9 @@ typedef struct bwamem_batch_s bwamem_batch_t; /* a request resident in HBM */
 
 /* upload a request buffer (same wire format as pSeq above); the host buffer is left untouched */
 bwamem_batch_t* bwamem_hip_batch_upload(bwaidx_t* idx, const char* pSeq, size_t nBytes);
+/* the same for a payload that already lives in HBM: d_payload = the NUL-terminated base strings (without the
+ * leading count), h_offsets = nReads+1 host offsets of the reads within it (h_offsets[nReads] = nBytes) */
+bwamem_batch_t* bwamem_hip_batch_wrap_device(bwaidx_t* idx, const void* d_payload, size_t nBytes, uint32_t nReads, const int64_t* h_offsets);
 /* run the whole hot path; results stay in HBM.  read_id0 = index of the first read within the
  * logical call (shards of one call must carry their global base index).  0 = ok. */
 int bwamem_hip_batch_align(bwaidx_t* idx, const mem_opt_t* opt, const mem_pestat_t* pes, bwamem_batch_t* b, int64_t read_id0);

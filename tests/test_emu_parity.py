@@ -1,0 +1,41 @@
+"""CPU-side check of the kernels' logic: the UNCHANGED product sources compiled against the
+host emulation of the HIP execution model in tests/emu/ (test infrastructure only; never
+shipped, never a fallback) must reproduce the oracle byte for byte.  Kept small: the fiber
+emulation of wavefront collectives is slow.  The real parity gate is tests/test_gpu_parity.py."""
+import os
+
+import pytest
+
+import bwalib as B
+
+
+@pytest.fixture(scope="module")
+def emu():
+    B.build_emu()
+    return B.product_lib(emu=True)
+
+
+def _cmp(emu, oracle, img, reads, **optkw):
+    h, ho = emu.open_index(img), oracle.open_index(img)
+    opts = B.set_opt(emu.default_options(), **optkw)
+    req = B.pack_request(reads)
+    got, want = emu.align_raw(h, opts, req), oracle.align_raw(ho, opts, req)
+    emu.destroy_index(h); oracle.destroy_index(ho)
+    assert got is not None
+    assert got == want
+
+
+def test_emu_golden_reads(emu, oracle, rota_img):
+    reads = [b"GGCTTTTAATGCTTTTCAGTGGTTGCTGCTCAAGATGGAGTCTACTCAGCAGATGGTAAGCTCTATTATT",
+             b"GGCTTTTAATGCTTTTCAGTGCTAGGTGCTCAAGATGGAGTCTACTCAGCAGATGGTAAGCTCTATTATT",
+             b"AATAATAGAGCTTACCATCTGCTGAGTAGACTCCATCTTGAGCAGCAACCACTGAAAAGCATTAAAAGCC",
+             b"AATACTTCTTTTGAAGCTGCAGTTGTTGCTGCCTTCAACATTAGAATTAATGGGTATTCAATATGATT", b"ACGT" * 20, b"N" * 30, b""]
+    _cmp(emu, oracle, rota_img, reads)
+
+
+def test_emu_small_genome(emu, oracle, small_genome):
+    seqs, img = small_genome
+    reads = B.simulate_reads(seqs, 24, length=150, seed=1, sub=0.02, indel=0.004, n_rate=0.002, random_frac=0.05)
+    reads += B.simulate_reads(seqs, 8, length=251, seed=3, sub=0.05, indel=0.01)
+    _cmp(emu, oracle, img, reads)
+    _cmp(emu, oracle, img, reads[:12], flag=B.MEM_F_ALL, w=10, T=20)
