@@ -101,7 +101,7 @@ struct DevCounters {
 };
 
 // per-tile error / overflow flags set by kernels, read back by the host after each stage
-enum { ERR_INTV_CAP = 1, ERR_OUT_CAP = 2, ERR_CIGAR_CAP = 4, ERR_LONG_READ = 8, ERR_SCRATCH = 16, ERR_BTREE = 32 };
+enum { ERR_INTV_CAP = 1, ERR_OUT_CAP = 2, ERR_CIGAR_CAP = 4, ERR_LONG_READ = 8, ERR_SCRATCH = 16, ERR_BTREE = 32, ERR_BAD_REG = 64 };
 
 struct TileView {
     // reads of this tile

@@ -1,0 +1,521 @@
+// k_pe.hip -- paired-end path: insert-size candidates, mate rescue, pairing, PE records.
+//
+// Replaces, for the reference call at jnibwa.c:214 with MEM_F_PE set (BwaMemAligner.java:73),
+// upstream bwamem_pair.c mem_pestat (candidate selection; the per-orientation statistics are a
+// batch-global reduction done on the host), mem_matesw + ksw.c ksw_align2, mem_pair and
+// mem_sam_pe.  One lane per read pair.  The local SW upstream is an SSE2
+// striped kernel whose observable quirks depend on the striping, so the striped layout is kept
+// (lane-by-lane, scalar) exactly as the oracle does.
+#include <math.h>
+#include "dev_common.h"
+#include "kernels.h"
+#include "post_common.h"
+
+
+// ------------------------------------------------------------------ insert-size candidates
+DEV int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t* dist)
+{
+    int r1 = (b1 >= l_pac), r2 = (b2 >= l_pac);
+    int64_t p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;
+    *dist = p2 > b1 ? p2 - b1 : b1 - p2;
+    return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
+}
+
+DEV int cal_sub(const MemOpt& opt, int n, const AlnReg* a)
+{
+    int j;
+    for (j = 1; j < n; ++j) {
+        int b_max = a[j].qb > a[0].qb ? a[j].qb : a[0].qb;
+        int e_min = a[j].qe < a[0].qe ? a[j].qe : a[0].qe;
+        if (e_min > b_max) {
+            int min_l = a[j].qe - a[j].qb < a[0].qe - a[0].qb ? a[j].qe - a[j].qb : a[0].qe - a[0].qb;
+            if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level) break;
+        }
+    }
+    return j < n ? a[j].score : opt.min_seed_len * opt.a;
+}
+
+// per pair: orientation (0..3, or -1) and insert size that mem_pestat would collect
+__global__ void k_pestat_cand(DevIndex ix, MemOpt opt, TileView tv, int8_t* cand_dir, int64_t* cand_is)
+{
+    int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= tv.n_reads >> 1) return;
+    int r0 = pi << 1, r1 = r0 | 1;
+    const AlnReg* a0 = tv.regs + tv.seed_off[r0];
+    const AlnReg* a1 = tv.regs + tv.seed_off[r1];
+    int n0 = tv.n_regs[r0], n1 = tv.n_regs[r1];
+    int dir = -1; int64_t is = 0;
+    if (n0 && n1 && !(cal_sub(opt, n0, a0) > 0.8 * a0[0].score) && !(cal_sub(opt, n1, a1) > 0.8 * a1[0].score) && a0[0].rid == a1[0].rid) {
+        int d = infer_dir(ix.l_pac, a0[0].rb, a1[0].rb, &is);
+        if (is && is <= opt.max_ins) dir = d;
+    }
+    cand_dir[pi] = (int8_t)dir; cand_is[pi] = is;
+}
+
+// ------------------------------------------------------------------ striped local SW (ksw_align2)
+#define KSW_XBYTE  0x10000
+#define KSW_XSTOP  0x20000
+#define KSW_XSUBO  0x40000
+#define KSW_XSTART 0x80000
+
+struct KswR { int score, te, qe, score2, te2, tb, qb; };
+
+struct SwIn {
+    const uint8_t* ms; int l_ms; int is_rev;     // query = ms or its reverse complement
+    int qrev;                                     // > 0: the first qrev query bases are read reversed (second pass)
+    int64_t t0; int trev;                         // target = reference from t0; the first trev bases reversed (second pass)
+};
+DEV int sw_q0(const SwIn& I, int i) { int c = I.is_rev ? I.ms[I.l_ms - 1 - i] : I.ms[i]; return I.is_rev ? (c < 4 ? 3 - c : 4) : c; }
+DEV int sw_q(const SwIn& I, int i) { return sw_q0(I, i < I.qrev ? I.qrev - 1 - i : i); }
+DEV int sw_t(const DevIndex& ix, const SwIn& I, int i) { return ref_base2(ix, I.t0 + (i < I.trev ? I.trev - 1 - i : i)); }
+
+struct SwScratch { int32_t* H0; int32_t* H1; int32_t* E; int32_t* Hmax; uint64_t* b; int cap_h, cap_b; };
+
+DEV int sat_u8(int x) { return x < 0 ? 0 : x > 255 ? 255 : x; }
+DEV int sat_i16(int x) { return x < -32768 ? -32768 : x > 32767 ? 32767 : x; }
+DEV int subs_u16(int a, int b) { int x = (int)(uint16_t)a - (int)(uint16_t)b; return x < 0 ? 0 : (int)(int16_t)(uint16_t)x; }
+
+DEV KswR sw_core(const DevIndex& ix, const MemOpt& opt, const SwIn& I, int size, int qlen, int tlen, int xtra, SwScratch& W, int& err)
+{
+    const int p = 8 * (3 - size), slen = (qlen + p - 1) / p, u8 = size == 1;
+    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    KswR r; r.score = 0; r.te = r.qe = r.score2 = r.te2 = r.tb = r.qb = -1;
+    if (slen * p > W.cap_h) { err |= ERR_SCRATCH; return r; }
+    int lo = 127, hi = 0;
+    for (int a = 0; a < 25; ++a) { if (opt.mat[a] < lo) lo = opt.mat[a]; if (opt.mat[a] > hi) hi = opt.mat[a]; }
+    const int shift = (256 - (lo & 0xff)) & 0xff, qmax = hi;
+    int n_b = 0, te = -1, gmax = 0;
+    const int minsc = (xtra & KSW_XSUBO) ? xtra & 0xffff : 0x10000;
+    const int endsc = (xtra & KSW_XSTOP) ? xtra & 0xffff : 0x10000;
+    int32_t *H0 = W.H0, *H1 = W.H1, *E = W.E, *Hmax = W.Hmax;
+    for (int i = 0; i < slen * p; ++i) { E[i] = 0; H0[i] = 0; Hmax[i] = 0; }
+    int h[16], f[16], mx[16];
+    for (int i = 0; i < tlen; ++i) {
+        const int tb = sw_t(ix, I, i);
+        int imax, done = 0;
+        for (int l = 0; l < p; ++l) { f[l] = 0; mx[l] = 0; }
+        h[0] = 0;
+        for (int l = 1; l < p; ++l) h[l] = H0[(slen - 1) * p + l - 1];
+        for (int j = 0; j < slen; ++j) {
+            for (int l = 0; l < p; ++l) {
+                int pos = j + l * slen;
+                int sc = (pos >= qlen ? 0 : opt.mat[tb * 5 + sw_q(I, pos)]) + (u8 ? shift : 0);
+                int hh, ee = E[j * p + l], t;
+                if (u8) { hh = sat_u8(h[l] + sc); hh = sat_u8(hh - shift); }
+                else hh = sat_i16(h[l] + sc);
+                hh = hh > ee ? hh : ee;
+                hh = hh > f[l] ? hh : f[l];
+                mx[l] = mx[l] > hh ? mx[l] : hh;
+                H1[j * p + l] = hh;
+                if (u8) { ee = sat_u8(ee - e_del); t = sat_u8(hh - oe_del); }
+                else    { ee = subs_u16(ee, e_del); t = subs_u16(hh, oe_del); }
+                ee = ee > t ? ee : t;
+                E[j * p + l] = ee;
+                if (u8) { f[l] = sat_u8(f[l] - e_ins); t = sat_u8(hh - oe_ins); }
+                else    { f[l] = subs_u16(f[l], e_ins); t = subs_u16(hh, oe_ins); }
+                f[l] = f[l] > t ? f[l] : t;
+                h[l] = H0[j * p + l];
+            }
+        }
+        for (int k = 0; k < 16 && !done; ++k) {          // lazy-F across segment boundaries
+            for (int l = p - 1; l > 0; --l) f[l] = f[l - 1];
+            f[0] = 0;
+            for (int j = 0; j < slen; ++j) {
+                int all = 1;
+                for (int l = 0; l < p; ++l) {
+                    int hh = H1[j * p + l];
+                    hh = hh > f[l] ? hh : f[l];
+                    H1[j * p + l] = hh;
+                    if (u8) { hh = sat_u8(hh - oe_ins); f[l] = sat_u8(f[l] - e_ins); if (sat_u8(f[l] - hh) != 0) all = 0; }
+                    else    { hh = subs_u16(hh, oe_ins); f[l] = subs_u16(f[l], e_ins); if (f[l] > hh) all = 0; }
+                }
+                if (all) { done = 1; break; }
+            }
+        }
+        imax = mx[0];
+        for (int l = 1; l < p; ++l) imax = imax > mx[l] ? imax : mx[l];
+        if (imax >= minsc) {
+            if (n_b == 0 || (int32_t)W.b[n_b - 1] + 1 != i) {
+                if (n_b >= W.cap_b) { err |= ERR_SCRATCH; return r; }
+                W.b[n_b++] = (uint64_t)imax << 32 | (uint32_t)i;
+            } else if ((int)(W.b[n_b - 1] >> 32) < imax) W.b[n_b - 1] = (uint64_t)imax << 32 | (uint32_t)i;
+        }
+        if (imax > gmax) {
+            gmax = imax; te = i;
+            for (int j = 0; j < slen * p; ++j) Hmax[j] = H1[j];
+            if (u8) { if (gmax + shift >= 255 || gmax >= endsc) break; }
+            else if (gmax >= endsc) break;
+        }
+        int32_t* S = H1; H1 = H0; H0 = S;
+    }
+    r.score = u8 ? (gmax + shift < 255 ? gmax : 255) : gmax;
+    r.te = te;
+    if (!u8 || r.score != 255) {
+        int max = -1, tmp, n = slen * p;
+        for (int i = 0; i < n; ++i) {
+            int v = Hmax[i];
+            if (v > max) { max = v; r.qe = i / p + i % p * slen; }
+            else if (v == max && (tmp = i / p + i % p * slen) < r.qe) r.qe = tmp;
+        }
+        if (n_b > 0) {
+            int i = (r.score + qmax - 1) / qmax;
+            int low = te - i, high = te + i;
+            for (i = 0; i < n_b; ++i) {
+                int e = (int32_t)W.b[i];
+                if ((e < low || e > high) && (int)(W.b[i] >> 32) > r.score2) { r.score2 = (int)(W.b[i] >> 32); r.te2 = e; }
+            }
+        }
+    }
+    return r;
+}
+
+DEV KswR sw_align2(const DevIndex& ix, const MemOpt& opt, SwIn I, int qlen, int tlen, int xtra, SwScratch& W, int& err)
+{
+    const int size = (xtra & KSW_XBYTE) ? 1 : 2;
+    I.qrev = 0; I.trev = 0;
+    KswR r = sw_core(ix, opt, I, size, qlen, tlen, xtra, W, err);
+    if ((xtra & KSW_XSTART) == 0 || ((xtra & KSW_XSUBO) && r.score < (xtra & 0xffff))) return r;
+    I.qrev = r.qe + 1; I.trev = r.te + 1;             // upstream reverses both prefixes in place, then runs over the full target
+    KswR rr = sw_core(ix, opt, I, size, r.qe + 1, tlen, KSW_XSTOP | r.score, W, err);
+    if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
+    return r;
+}
+
+// ------------------------------------------------------------------ mate rescue (mem_matesw)
+DEV int matesw(const DevIndex& ix, const MemOpt& opt, PostScratch& S, SwScratch& W, const MemPestat* pes, const AlnReg& a,
+               int l_ms, const uint8_t* ms, int& n_ma, AlnReg* ma, int cap_ma, int& err)
+{
+    const int64_t l_pac = ix.l_pac;
+    int i, r, skip[4], n = 0, rid = -1;
+    for (r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
+    for (i = 0; i < n_ma; ++i) {
+        int64_t dist;
+        r = infer_dir(l_pac, a.rb, ma[i].rb, &dist);
+        if (dist >= pes[r].low && dist <= pes[r].high) skip[r] = 1;
+    }
+    if (skip[0] + skip[1] + skip[2] + skip[3] == 4) return 0;
+    for (r = 0; r < 4; ++r) {
+        if (skip[r]) continue;
+        int is_rev = (r >> 1 != (r & 1));
+        int is_larger = !(r >> 1);
+        int64_t rb, re;
+        if (!is_rev) {
+            rb = is_larger ? a.rb + pes[r].low : a.rb - pes[r].high;
+            re = (is_larger ? a.rb + pes[r].high : a.rb - pes[r].low) + l_ms;
+        } else {
+            rb = (is_larger ? a.rb + pes[r].low : a.rb - pes[r].high) - l_ms;
+            re = is_larger ? a.rb + pes[r].high : a.rb - pes[r].low;
+        }
+        if (rb < 0) rb = 0;
+        if (re > l_pac << 1) re = l_pac << 1;
+        if (rb < re) bns_clamp(ix, rb, (rb + re) >> 1, re, rid);
+        if (a.rid == rid && re - rb >= opt.min_seed_len) {
+            int xtra = KSW_XSUBO | KSW_XSTART | (l_ms * opt.a < 250 ? KSW_XBYTE : 0) | (opt.min_seed_len * opt.a);
+            SwIn I; I.ms = ms; I.l_ms = l_ms; I.is_rev = is_rev; I.qrev = 0; I.t0 = rb; I.trev = 0;
+            KswR aln = sw_align2(ix, opt, I, l_ms, (int)(re - rb), xtra, W, err);
+            if (aln.score >= opt.min_seed_len && aln.qb >= 0) {
+                AlnReg b;
+                b.rb = b.re = 0; b.qb = b.qe = 0; b.rid = 0; b.score = b.truesc = b.sub = b.alt_sc = b.csub = b.sub_n = b.w = b.seedcov = 0;
+                b.secondary = b.secondary_all = b.seedlen0 = b.n_comp = b.is_alt = 0; b.frac_rep = 0.f; b.pad_ = 0; b.hash = 0;
+                b.rid = a.rid;
+                b.is_alt = a.is_alt;
+                b.qb = is_rev ? l_ms - (aln.qe + 1) : aln.qb;
+                b.qe = is_rev ? l_ms - aln.qb : aln.qe + 1;
+                b.rb = is_rev ? (l_pac << 1) - (rb + aln.te + 1) : rb + aln.tb;
+                b.re = is_rev ? (l_pac << 1) - (rb + aln.tb) : rb + aln.te + 1;
+                b.score = aln.score;
+                b.csub = aln.score2;
+                b.secondary = -1;
+                b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+                if (n_ma >= cap_ma) { err |= ERR_SCRATCH; return n; }
+                ++n_ma;
+                for (i = 0; i < n_ma - 1; ++i) if (ma[i].score < b.score) break;
+                int tmp = i;
+                for (i = n_ma - 1; i > tmp; --i) ma[i] = ma[i - 1];
+                ma[i] = b;
+            }
+            ++n;
+        }
+        if (n) n_ma = sort_dedup_patch(ix, opt, S, 0, n_ma, ma);
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------ pairing (mem_pair)
+struct Pair64 { uint64_t x, y; };
+struct Pair64Lt { __device__ bool operator()(const Pair64& a, const Pair64& b) const { return a.x < b.x || (a.x == b.x && a.y < b.y); } };
+
+DEV int mem_pair(const DevIndex& ix, const MemOpt& opt, const MemPestat* pes, const AlnReg* a0, const AlnReg* a1, int id,
+                 int* sub, int* n_sub, int z[2], const int n_pri[2], Pair64* v, Pair64* u, int cap_u, int& err)
+{
+    const int64_t l_pac = ix.l_pac;
+    int r, i, k, y[4], ret, nv = 0, nu = 0;
+    for (r = 0; r < 2; ++r) {
+        const AlnReg* a = r ? a1 : a0;
+        for (i = 0; i < n_pri[r]; ++i) {
+            Pair64 key;
+            const AlnReg* e = &a[i];
+            key.x = (uint64_t)(e->rb < l_pac ? e->rb : (l_pac << 1) - 1 - e->rb);
+            key.x = (uint64_t)e->rid << 32 | (key.x - (uint64_t)ix.ann_offset[e->rid]);
+            key.y = (uint64_t)e->score << 32 | (uint64_t)(int64_t)(i << 2 | (e->rb >= l_pac) << 1 | r);
+            v[nv++] = key;
+        }
+    }
+    ks_introsort((size_t)nv, v, Pair64Lt());
+    y[0] = y[1] = y[2] = y[3] = -1;
+    for (i = 0; i < nv; ++i) {
+        for (r = 0; r < 2; ++r) {
+            int dir = r << 1 | (int)(v[i].y >> 1 & 1), which;
+            if (pes[dir].failed) continue;
+            which = r << 1 | (int)((v[i].y & 1) ^ 1);
+            if (y[which] < 0) continue;
+            for (k = y[which]; k >= 0; --k) {
+                int64_t dist;
+                int q;
+                double ns;
+                if ((int)(v[k].y & 3) != which) continue;
+                dist = (int64_t)v[i].x - (int64_t)v[k].x;
+                if (dist > pes[dir].high) break;
+                if (dist < pes[dir].low) continue;
+                ns = (dist - pes[dir].avg) / pes[dir].std;
+                q = (int)((v[i].y >> 32) + (v[k].y >> 32) + .721 * log(2. * erfc(fabs(ns) * 0.70710678118654752440)) * opt.a + .499);
+                if (q < 0) q = 0;
+                if (nu >= cap_u) { err |= ERR_SCRATCH; return 0; }
+                Pair64* p = &u[nu++];
+                p->y = (uint64_t)k << 32 | (uint64_t)i;
+                p->x = (uint64_t)q << 32 | (hash_64(p->y ^ (uint64_t)(int64_t)(id << 8)) & 0xffffffffU);
+            }
+        }
+        y[v[i].y & 3] = i;
+    }
+    if (nu) {
+        int tmp = opt.a + opt.b;
+        tmp = tmp > opt.o_del + opt.e_del ? tmp : opt.o_del + opt.e_del;
+        tmp = tmp > opt.o_ins + opt.e_ins ? tmp : opt.o_ins + opt.e_ins;
+        ks_introsort((size_t)nu, u, Pair64Lt());
+        i = (int)(u[nu - 1].y >> 32); k = (int)(u[nu - 1].y << 32 >> 32);
+        z[v[i].y & 1] = (int)(v[i].y << 32 >> 34);
+        z[v[k].y & 1] = (int)(v[k].y << 32 >> 34);
+        ret = (int)(u[nu - 1].x >> 32);
+        *sub = nu > 1 ? (int)(u[nu - 2].x >> 32) : 0;
+        for (i = nu - 2, *n_sub = 0; i >= 0; --i)
+            if (*sub - (int)(u[i].x >> 32) <= tmp) ++*n_sub;
+    } else { ret = 0; *sub = 0; *n_sub = 0; }
+    return ret;
+}
+
+DEV MateInfo mate_of(const AlnRec& h) { MateInfo m; m.rid = h.rid; m.pos = h.pos; m.is_rev = h.is_rev; m.ref_len = h.ref_len; return m; }
+
+#define RAW_MAPQ(diff, a) ((int)(6.02 * (diff) / (a) + .499))
+
+// per-pair scratch layout handed to k_final_pe
+struct PeView {
+    AlnReg* regs;             // pool with room for rescued regions
+    const int64_t* reg_off;   // [n_reads+1]
+    int32_t* n_regs;          // [n_reads] in/out
+    int32_t* ints;            // 2 ints per region slot (zbuf)
+    uint8_t* scratch;         // per pair
+    int64_t scratch_per_pair;
+    void* vpool;              // Pair64 per region slot (indexed by reg_off of the pair's first read)
+    int cap_h, cap_b, cap_u;
+};
+
+__global__ void k_final_pe(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3)
+{
+    int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= tv.n_reads >> 1) return;
+    const MemPestat pes[4] = { p0, p1, p2, p3 };
+    const int rd[2] = { pi << 1, pi << 1 | 1 };
+    PostScratch S = post_scratch_for(tv, rd[0]);
+    int err = 0;
+    const uint8_t* seq[2]; int l_seq[2]; AlnReg* a[2]; int n[2], cap[2]; int32_t* zb[2]; OutBuf ob[2];
+    for (int i = 0; i < 2; ++i) {
+        seq[i] = tv.seq + tv.seq_off[rd[i]];
+        l_seq[i] = (int)(tv.seq_off[rd[i] + 1] - tv.seq_off[rd[i]] - 1);
+        a[i] = pv.regs + pv.reg_off[rd[i]];
+        cap[i] = (int)(pv.reg_off[rd[i] + 1] - pv.reg_off[rd[i]]);
+        n[i] = pv.n_regs[rd[i]];
+        zb[i] = pv.ints + 2 * pv.reg_off[rd[i]];
+        ob[i].p = tv.out + (size_t)rd[i] * tv.out_cap; ob[i].cap = tv.out_cap; ob[i].len = 0; ob[i].ovf = false;
+    }
+    // scratch carve-up
+    uint8_t* sp = pv.scratch + (size_t)pi * pv.scratch_per_pair;
+    SwScratch W;
+    W.cap_h = pv.cap_h; W.cap_b = pv.cap_b;
+    W.H0 = (int32_t*)sp; sp += (size_t)W.cap_h * 4; W.H1 = (int32_t*)sp; sp += (size_t)W.cap_h * 4;
+    W.E = (int32_t*)sp; sp += (size_t)W.cap_h * 4; W.Hmax = (int32_t*)sp; sp += (size_t)W.cap_h * 4;
+    W.b = (uint64_t*)sp; sp += (size_t)W.cap_b * 8;
+    AlnReg* anchors[2]; int n_anch[2];
+    anchors[0] = (AlnReg*)sp; sp += (size_t)opt.max_matesw * sizeof(AlnReg);
+    anchors[1] = (AlnReg*)sp; sp += (size_t)opt.max_matesw * sizeof(AlnReg);
+    Pair64* v = (Pair64*)pv.vpool + pv.reg_off[rd[0]];      // cap[0] + cap[1] entries >= n_pri[0] + n_pri[1]
+    Pair64* u = (Pair64*)sp;
+    const int cap_u = pv.cap_u;
+
+    const uint64_t id = (uint64_t)((tv.read_id0 >> 1) + pi);
+    int z[2] = { 0, 0 }, o = 0, subo = 0, n_sub = 0, extra_flag = 1, n_pri[2];
+    if (!(opt.flag & MEM_F_NO_RESCUE)) {                       // mate rescue from the best hits of each end
+        for (int i = 0; i < 2; ++i) {
+            n_anch[i] = 0;
+            for (int j = 0; j < n[i]; ++j)
+                if (a[i][j].score >= a[i][0].score - opt.pen_unpaired) { if (n_anch[i] < opt.max_matesw) anchors[i][n_anch[i]] = a[i][j]; ++n_anch[i]; }
+        }
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < n_anch[i] && j < opt.max_matesw; ++j)
+                matesw(ix, opt, S, W, pes, anchors[i][j], l_seq[!i], seq[!i], n[!i], a[!i], cap[!i], err);
+    }
+    n_pri[0] = mark_primary_se(opt, n[0], a[0], (int64_t)(id << 1 | 0), zb[0]);
+    n_pri[1] = mark_primary_se(opt, n[1], a[1], (int64_t)(id << 1 | 1), zb[1]);
+    if (opt.flag & MEM_F_PRIMARY5) { reorder_primary5(opt.T, n[0], a[0]); reorder_primary5(opt.T, n[1], a[1]); }
+
+    bool paired = false;
+    if (!(opt.flag & MEM_F_NOPAIRING) && n_pri[0] && n_pri[1]
+        && (o = mem_pair(ix, opt, pes, a[0], a[1], (int)id, &subo, &n_sub, z, n_pri, v, u, cap_u, err)) > 0) {
+        int is_multi[2], q_pe, score_un, q_se[2];
+        for (int i = 0; i < 2; ++i) {
+            int j;
+            for (j = 1; j < n_pri[i]; ++j)
+                if (a[i][j].secondary < 0 && a[i][j].score >= opt.T) break;
+            is_multi[i] = j < n_pri[i] ? 1 : 0;
+        }
+        if (!(is_multi[0] || is_multi[1])) {
+            paired = true;
+            score_un = a[0][0].score + a[1][0].score - opt.pen_unpaired;
+            subo = subo > score_un ? subo : score_un;
+            q_pe = RAW_MAPQ(o - subo, opt.a);
+            if (n_sub > 0) {
+                if (n_sub + 1 >= ix.log_tab_n) err |= ERR_SCRATCH;
+                else q_pe -= (int)(4.343 * ix.log_tab[n_sub + 1] + .499);
+            }
+            if (q_pe < 0) q_pe = 0;
+            if (q_pe > 60) q_pe = 60;
+            q_pe = (int)(q_pe * (1. - .5 * (a[0][0].frac_rep + a[1][0].frac_rep)) + .499);
+            if (o > score_un) {                                 // the paired alignment is preferred
+                AlnReg* c[2] = { &a[0][z[0]], &a[1][z[1]] };
+                for (int i = 0; i < 2; ++i) {
+                    if (c[i]->secondary >= 0) { c[i]->sub = a[i][c[i]->secondary].score; c[i]->secondary = -2; }
+                    q_se[i] = approx_mapq_se(ix, opt, S, *c[i]);
+                }
+                q_se[0] = q_se[0] > q_pe ? q_se[0] : q_pe < q_se[0] + 40 ? q_pe : q_se[0] + 40;
+                q_se[1] = q_se[1] > q_pe ? q_se[1] : q_pe < q_se[1] + 40 ? q_pe : q_se[1] + 40;
+                extra_flag |= 2;
+                q_se[0] = q_se[0] < RAW_MAPQ(c[0]->score - c[0]->csub, opt.a) ? q_se[0] : RAW_MAPQ(c[0]->score - c[0]->csub, opt.a);
+                q_se[1] = q_se[1] < RAW_MAPQ(c[1]->score - c[1]->csub, opt.a) ? q_se[1] : RAW_MAPQ(c[1]->score - c[1]->csub, opt.a);
+            } else {
+                z[0] = z[1] = 0;
+                q_se[0] = approx_mapq_se(ix, opt, S, a[0][0]);
+                q_se[1] = approx_mapq_se(ix, opt, S, a[1][0]);
+            }
+            for (int i = 0; i < 2; ++i) {
+                int k = a[i][z[i]].secondary_all;
+                if (k >= 0 && k < n_pri[i]) {                   // swap primary and secondary when both are non-ALT
+                    for (int j = 0; j < n[i]; ++j)
+                        if (a[i][j].secondary_all == k || j == k) a[i][j].secondary_all = z[i];
+                    a[i][z[i]].secondary_all = -1;
+                }
+            }
+            // records: h[i] (+ an ALT supplementary g[i]); each needs the mate's position
+            MateInfo hm[2];
+            int n_aa[2] = { 1, 1 }, alt_k[2] = { -1, -1 };
+            for (int i = 0; i < 2; ++i) {
+                AlnRec h = reg2aln(ix, opt, S, l_seq[i], seq[i], &a[i][z[i]]);
+                hm[i] = mate_of(h);
+                if (n_pri[i] < n[i]) {
+                    const AlnReg* p = &a[i][n_pri[i]];
+                    if (!(p->score < opt.T || p->secondary >= 0 || !p->is_alt)) { alt_k[i] = n_pri[i]; n_aa[i] = 2; }
+                }
+            }
+            for (int i = 0; i < 2; ++i) {
+                int32_t *cnt = 0, *has_alt = 0;
+                if (!(opt.flag & MEM_F_ALL) && n[i] > 0) {
+                    cnt = zb[i]; has_alt = zb[i] + n[i];
+                    if (xa_prepare(opt, n[i], a[i], cnt, has_alt) == 0) cnt = has_alt = 0;
+                }
+                AlnRec h = reg2aln(ix, opt, S, l_seq[i], seq[i], &a[i][z[i]]);
+                h.mapq = q_se[i];
+                h.flag |= 0x40 << i | extra_flag;
+                aln2out(ix, opt, S, ob[i], n_aa[i], 0, h, &hm[!i], l_seq[i], seq[i], n[i], a[i], cnt, has_alt, cnt ? z[i] : -1);
+                if (alt_k[i] >= 0) {
+                    AlnRec g = reg2aln(ix, opt, S, l_seq[i], seq[i], &a[i][alt_k[i]]);
+                    g.flag |= 0x800 | 0x40 << i | extra_flag;
+                    aln2out(ix, opt, S, ob[i], n_aa[i], 1, g, &hm[!i], l_seq[i], seq[i], n[i], a[i], cnt, has_alt, cnt ? alt_k[i] : -1);
+                }
+            }
+        }
+    }
+    if (!paired) {                                              // no_pairing
+        MateInfo hm[2];
+        int hrid[2];
+        for (int i = 0; i < 2; ++i) {
+            int which = -1;
+            if (n[i]) {
+                if (a[i][0].score >= opt.T) which = 0;
+                else if (n_pri[i] < n[i] && a[i][n_pri[i]].score >= opt.T) which = n_pri[i];
+            }
+            AlnRec h = reg2aln(ix, opt, S, l_seq[i], seq[i], which >= 0 ? &a[i][which] : 0);
+            hm[i] = mate_of(h); hrid[i] = h.rid;
+        }
+        if (!(opt.flag & MEM_F_NOPAIRING) && hrid[0] == hrid[1] && hrid[0] >= 0) {
+            int64_t dist;
+            int d = infer_dir(ix.l_pac, a[0][0].rb, a[1][0].rb, &dist);
+            if (!pes[d].failed && dist >= pes[d].low && dist <= pes[d].high) extra_flag |= 2;
+        }
+        reg2sam(ix, opt, S, ob[0], l_seq[0], seq[0], n[0], a[0], zb[0], 0x41 | extra_flag, &hm[1]);
+        reg2sam(ix, opt, S, ob[1], l_seq[1], seq[1], n[1], a[1], zb[1], 0x81 | extra_flag, &hm[0]);
+    }
+    for (int i = 0; i < 2; ++i) {
+        pv.n_regs[rd[i]] = n[i];
+        tv.out_len[rd[i]] = ob[i].ovf ? 0 : ob[i].len;
+        if (ob[i].ovf) atomicOr(tv.err, ERR_OUT_CAP);
+    }
+    if (S.err | err) atomicOr(tv.err, S.err | err);
+}
+
+// an odd trailing read of a PE call is never processed upstream (n>>1 pairs): it produces no bytes
+__global__ void k_pe_tail(TileView tv) { if (threadIdx.x == 0 && blockIdx.x == 0 && (tv.n_reads & 1)) tv.out_len[tv.n_reads - 1] = 0; }
+
+// capacity of each read's region pool in phase 2: its own regions + what mate rescue may add
+__global__ void k_pe_caps(MemOpt opt, TileView tv, int32_t* caps)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= tv.n_reads) return;
+    int mate = r ^ 1;
+    int nm = mate < tv.n_reads ? tv.n_regs[mate] : 0;
+    caps[r] = tv.n_regs[r] + 4 * (nm < opt.max_matesw ? nm : opt.max_matesw) + 1;
+}
+
+// regions from the phase-1 pool (indexed by seed_off) into the phase-2 pool (indexed by reg_off)
+__global__ void k_pe_copy_regs(TileView tv, const AlnReg* src, const int64_t* src_off, AlnReg* dst, const int64_t* dst_off, const int32_t* n_regs)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= tv.n_reads) return;
+    for (int i = 0; i < n_regs[r]; ++i) dst[dst_off[r] + i] = src[src_off[r] + i];
+}
+
+void launch_pestat_cand(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, int8_t* cand_dir, int64_t* cand_is)
+{
+    int np = tv.n_reads >> 1;
+    if (np <= 0) return;
+    hipLaunchKernelGGL(k_pestat_cand, dim3((np + 63) / 64), dim3(64), 0, st, ix, opt, tv, cand_dir, cand_is);
+}
+void launch_pe_caps(hipStream_t st, const MemOpt& opt, const TileView& tv, int32_t* caps)
+{
+    if (tv.n_reads <= 0) return;
+    hipLaunchKernelGGL(k_pe_caps, dim3((tv.n_reads + 255) / 256), dim3(256), 0, st, opt, tv, caps);
+}
+void launch_pe_copy_regs(hipStream_t st, const TileView& tv, const AlnReg* src, const int64_t* src_off, AlnReg* dst, const int64_t* dst_off, const int32_t* n_regs)
+{
+    if (tv.n_reads <= 0) return;
+    hipLaunchKernelGGL(k_pe_copy_regs, dim3((tv.n_reads + 255) / 256), dim3(256), 0, st, tv, src, src_off, dst, dst_off, n_regs);
+}
+void launch_final_pe(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, AlnReg* regs, const int64_t* reg_off,
+                     int32_t* n_regs, int32_t* ints, void* vpool, uint8_t* scratch, int64_t scratch_per_pair, int cap_h, int cap_b, int cap_u, const MemPestat* pes)
+{
+    int np = tv.n_reads >> 1;
+    hipLaunchKernelGGL(k_pe_tail, dim3(1), dim3(64), 0, st, tv);
+    if (np <= 0) return;
+    PeView pv; pv.regs = regs; pv.reg_off = reg_off; pv.n_regs = n_regs; pv.ints = ints; pv.vpool = vpool; pv.scratch = scratch;
+    pv.scratch_per_pair = scratch_per_pair; pv.cap_h = cap_h; pv.cap_b = cap_b; pv.cap_u = cap_u;
+    hipLaunchKernelGGL(k_final_pe, dim3((np + 63) / 64), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3]);
+}

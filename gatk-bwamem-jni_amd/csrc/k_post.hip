@@ -10,80 +10,6 @@
 #include "kernels.h"
 #include "post_common.h"
 
-// ------------------------------------------------------------------ sort comparators
-struct RegReLt { __device__ bool operator()(const AlnReg& a, const AlnReg& b) const { return a.re < b.re; } };
-struct RegSLt  { __device__ bool operator()(const AlnReg& a, const AlnReg& b) const {
-    return a.score > b.score || (a.score == b.score && (a.rb < b.rb || (a.rb == b.rb && a.qb < b.qb))); } };
-
-// mem_patch_reg: can two colinear regions be merged into one global alignment?
-DEV int patch_reg(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const uint8_t* query, const AlnReg& a, const AlnReg& b, int* _w)
-{
-    if (a.rb < ix.l_pac && b.rb >= ix.l_pac) return 0;
-    if (a.qb >= b.qb || a.qe >= b.qe || a.re >= b.re) return 0;
-    int w = (int)((a.re - b.rb) - (a.qe - b.qb));
-    w = w > 0 ? w : -w;
-    double r = (double)(a.re - b.rb) / (b.re - a.rb) - (double)(a.qe - b.qb) / (b.qe - a.qb);
-    r = r > 0. ? r : -r;
-    if (a.re < b.rb || a.qe < b.qb) {
-        if (w > opt.w << 1 || r >= 0.05f) return 0;
-    } else if (w > opt.w << 2 || r >= 0.05f * 2) return 0;
-    w += a.w + b.w;
-    w = w < opt.w << 2 ? w : opt.w << 2;
-    int score = 0;
-    gen_cigar2(ix, opt, S, w, b.qe - a.qb, query + a.qb, a.rb, b.re, &score, false, 0, 0);
-    int q_s = (int)((double)(b.qe - a.qb) / ((b.qe - b.qb) + (a.qe - a.qb)) * (b.score + a.score) + .499);
-    int r_s = (int)((double)(b.re - a.rb) / ((b.re - b.rb) + (a.re - a.rb)) * (b.score + a.score) + .499);
-    if ((double)score / (q_s > r_s ? q_s : r_s) < 0.90f) return 0;
-    *_w = w;
-    return score;
-}
-
-// mem_sort_dedup_patch; query == 0 disables patching (the mate-rescue caller)
-__device__ int sort_dedup_patch(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const uint8_t* query, int n, AlnReg* a)
-{
-    int m, i, j;
-    if (n <= 1) return n;
-    ks_introsort((size_t)n, a, RegReLt());
-    for (i = 0; i < n; ++i) a[i].n_comp = 1;
-    for (i = 1; i < n; ++i) {
-        AlnReg* p = &a[i];
-        if (p->rid != a[i - 1].rid || p->rb >= a[i - 1].re + opt.max_chain_gap) continue;
-        for (j = i - 1; j >= 0 && p->rid == a[j].rid && p->rb < a[j].re + opt.max_chain_gap; --j) {
-            AlnReg* q = &a[j];
-            int64_t orr, oq, mr, mq;
-            int score, w;
-            if (q->qe == q->qb) continue;
-            orr = q->re - p->rb;
-            oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
-            mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
-            mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
-            if ((float)orr > opt.mask_level_redun * (float)mr && (float)oq > opt.mask_level_redun * (float)mq) {
-                if (p->score < q->score) { p->qe = p->qb; break; }
-                else q->qe = q->qb;
-            } else if (query && q->rb < p->rb && (score = patch_reg(ix, opt, S, query, *q, *p, &w)) > 0) {
-                p->n_comp += q->n_comp + 1;
-                p->seedcov = p->seedcov > q->seedcov ? p->seedcov : q->seedcov;
-                p->sub = p->sub > q->sub ? p->sub : q->sub;
-                p->csub = p->csub > q->csub ? p->csub : q->csub;
-                p->qb = q->qb; p->rb = q->rb;
-                p->truesc = p->score = score;
-                p->w = w;
-                q->qb = q->qe;
-            }
-        }
-    }
-    for (i = 0, m = 0; i < n; ++i)
-        if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
-    n = m;
-    ks_introsort((size_t)n, a, RegSLt());
-    for (i = 1; i < n; ++i)
-        if (a[i].score == a[i - 1].score && a[i].rb == a[i - 1].rb && a[i].qb == a[i - 1].qb)
-            a[i].qe = a[i].qb;
-    for (i = 1, m = 1; i < n; ++i)
-        if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
-    return m;
-}
-
 __global__ void k_post1(DevIndex ix, MemOpt opt, TileView tv)
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -91,6 +17,19 @@ __global__ void k_post1(DevIndex ix, MemOpt opt, TileView tv)
     PostScratch S = post_scratch_for(tv, r);
     const uint8_t* query = tv.seq + tv.seq_off[r];
     AlnReg* a = tv.regs + tv.seed_off[r];
+    {   // regions must be sane before any loop is sized from them: fail the call loudly instead of spinning
+        const int l_query = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
+        const int n0 = tv.n_regs[r];
+        bool bad = n0 < 0 || n0 > tv.seed_off[r + 1] - tv.seed_off[r];
+        for (int i = 0; !bad && i < n0; ++i)
+            bad = a[i].qb < 0 || a[i].qe < a[i].qb || a[i].qe > l_query || a[i].rb < 0 || a[i].re < a[i].rb || a[i].re > ix.l_pac << 1
+               || a[i].re - a[i].rb > 4 * (int64_t)l_query + 1024 || a[i].rid < 0 || a[i].rid >= ix.n_seqs;
+        if (bad) {
+            if (!(atomicOr(tv.err, ERR_BAD_REG) & ERR_BAD_REG)) { tv.err[1] = r; tv.err[2] = n0; if (n0 > 0) { tv.err[3] = a[0].qb; tv.err[4] = a[0].qe; tv.err[5] = (int)a[0].rb; tv.err[6] = (int)a[0].re; tv.err[7] = a[0].score; } }
+            tv.n_regs[r] = 0;
+            return;
+        }
+    }
     int n = sort_dedup_patch(ix, opt, S, query, tv.n_regs[r], a);
     for (int i = 0; i < n; ++i)
         if (a[i].rid >= 0 && ix.ann_is_alt[a[i].rid]) a[i].is_alt = 1;

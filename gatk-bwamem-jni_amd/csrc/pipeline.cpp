@@ -234,18 +234,237 @@ static int64_t post_bytes_per_read(int L, const MemOpt& opt)
     return ((fixed + ncol * tl) + 63) & ~(int64_t)63;
 }
 
+
+// BWAMEM_HIP_DUMP=1 (tiles of <= 64 reads): print chains and regions after extension (debugging aid only)
+static void debug_dump(Workspace& ws, const TileView& tv, int T)
+{
+    (void)hipStreamSynchronize(ws.stream);
+    std::vector<int64_t> so(T + 1); std::vector<int32_t> nc(T), nr(T);
+    (void)hipMemcpy(so.data(), tv.seed_off, (T + 1) * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(nc.data(), tv.n_chains, T * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(nr.data(), tv.n_regs, T * 4, hipMemcpyDeviceToHost);
+    for (int r = 0; r < T; ++r) {
+        int64_t ns = so[r + 1] - so[r];
+        fprintf(stderr, "[dump] read %d: seeds=%lld chains=%d regs=%d\n", r, (long long)ns, nc[r], nr[r]);
+        if (ns <= 0 || ns > 4096) continue;
+        std::vector<Chain> ch(ns); std::vector<Seed> cs(ns); std::vector<AlnReg> rg(ns);
+        (void)hipMemcpy(ch.data(), tv.chains + so[r], ns * sizeof(Chain), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(cs.data(), tv.cseeds + so[r], ns * sizeof(Seed), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(rg.data(), tv.regs + so[r], ns * sizeof(AlnReg), hipMemcpyDeviceToHost);
+        for (int i = 0; i < nc[r] && i < ns; ++i) {
+            fprintf(stderr, "[dump]   chain %d: pos=%lld n=%d rid=%d w=%u kept=%d seed0=%d\n", i, (long long)ch[i].pos, ch[i].n, ch[i].rid, ch[i].w, ch[i].kept, ch[i].seed0);
+            for (int j = 0; j < ch[i].n && ch[i].seed0 + j < ns; ++j) { const Seed& s = cs[ch[i].seed0 + j]; fprintf(stderr, "[dump]     seed rbeg=%lld qbeg=%d len=%d score=%d\n", (long long)s.rbeg, s.qbeg, s.len, s.score); }
+        }
+        for (int i = 0; i < nr[r] && i < ns; ++i)
+            fprintf(stderr, "[dump]   reg %d: rb=%lld re=%lld qb=%d qe=%d rid=%d score=%d truesc=%d w=%d seedcov=%d seedlen0=%d\n", i, (long long)rg[i].rb, (long long)rg[i].re,
+                    rg[i].qb, rg[i].qe, rg[i].rid, rg[i].score, rg[i].truesc, rg[i].w, rg[i].seedcov, rg[i].seedlen0);
+    }
+    fflush(stderr);
+}
+
+// ------------------------------------------------------------------------------------------ paired-end flow
+// Phase 1 (per tile): seeding .. region de-duplication, exactly as single-end; the regions of every tile are
+// kept compact in HBM.  Then the batch-global insert-size statistics (mem_pestat) are reduced on the host
+// from per-pair (orientation, insert size) candidates -- the one cross-read dependency of the path
+//  -- and phase 2 (per tile) does mate rescue, pairing and record generation.
+struct PeTile { uint32_t r0 = 0; int T = 0, L = 0; DevBuf n_regs, regs, reg_off; int64_t n_regs_total = 0; };
+
+static void host_pestat(const MemOpt& opt, const std::vector<int8_t>& dir, const std::vector<int64_t>& is, MemPestat pes[4])
+{   // upstream mem_pestat after candidate collection (bwamem_pair.c); candidates arrive in pair order
+    std::vector<uint64_t> isize[4];
+    for (size_t i = 0; i < dir.size(); ++i) if (dir[i] >= 0) isize[(int)dir[i]].push_back((uint64_t)is[i]);
+    memset(pes, 0, 4 * sizeof(MemPestat));
+    for (int d = 0; d < 4; ++d) {
+        MemPestat* r = &pes[d];
+        std::vector<uint64_t>& q = isize[d];
+        if (q.size() < 10) { r->failed = 1; continue; }
+        std::sort(q.begin(), q.end());
+        int p25 = (int)q[(int)(.25 * q.size() + .499)];
+        int p75 = (int)q[(int)(.75 * q.size() + .499)];
+        r->low = (int)(p25 - 2.0 * (p75 - p25) + .499);
+        if (r->low < 1) r->low = 1;
+        r->high = (int)(p75 + 2.0 * (p75 - p25) + .499);
+        size_t x = 0;
+        r->avg = 0;
+        for (size_t i = 0; i < q.size(); ++i) if (q[i] >= (uint64_t)r->low && q[i] <= (uint64_t)r->high) { r->avg += q[i]; ++x; }
+        r->avg /= x;
+        r->std = 0;
+        for (size_t i = 0; i < q.size(); ++i) if (q[i] >= (uint64_t)r->low && q[i] <= (uint64_t)r->high) r->std += (q[i] - r->avg) * (q[i] - r->avg);
+        r->std = sqrt(r->std / x);
+        r->low  = (int)(p25 - 3.0 * (p75 - p25) + .499);
+        r->high = (int)(p75 + 3.0 * (p75 - p25) + .499);
+        if (r->low  > r->avg - 4.0 * r->std) r->low  = (int)(r->avg - 4.0 * r->std + .499);
+        if (r->high < r->avg + 4.0 * r->std) r->high = (int)(r->avg + 4.0 * r->std + .499);
+        if (r->low < 1) r->low = 1;
+    }
+    size_t mx = 0;
+    for (int d = 0; d < 4; ++d) mx = std::max(mx, isize[d].size());
+    for (int d = 0; d < 4; ++d) if (pes[d].failed == 0 && isize[d].size() < mx * 0.05) pes[d].failed = 1;
+}
+
+static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes0, bwamem_batch_s* b, int64_t read_id0)
+{
+    Workspace& ws = ix->ws;
+    const char* env_t = getenv("BWAMEM_HIP_TILE");
+    std::vector<PeTile*> tiles;
+    std::vector<int8_t> cand_dir; std::vector<int64_t> cand_is;
+    DevBuf d_dir, d_is, caps, reg_off2, regs2, ints2, vpool, pe_scratch;
+    bool ok = false;
+    int intv_cap_scale = 1, out_cap = 512;
+    auto cleanup = [&]() {
+        for (PeTile* t : tiles) { t->n_regs.release(); t->regs.release(); t->reg_off.release(); delete t; }
+        d_dir.release(); d_is.release(); caps.release(); reg_off2.release(); regs2.release(); ints2.release(); vpool.release(); pe_scratch.release();
+    };
+#define PE_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "[bwamem_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); cleanup(); return false; } } while (0)
+#define PE_REQ(cond) do { if (!(cond)) { cleanup(); return false; } } while (0)
+    // ---------------- phase 1
+    uint32_t r0 = 0;
+    while (r0 < b->n_reads) {
+        int64_t budget = (int64_t)24 << 30;
+        int L0 = 1; uint32_t r1 = r0;
+        uint32_t max_T = env_t ? (uint32_t)atoi(env_t) : 262144u;
+        max_T = std::max(2u, max_T & ~1u);
+        while (r1 < b->n_reads && r1 - r0 < max_T) {
+            int len = (int)(b->h_off[r1 + 1] - b->h_off[r1] - 1);
+            int L1 = std::max(L0, len);
+            int icap = std::max(64, L1 + 8) * intv_cap_scale;
+            int64_t pr = (int64_t)icap * (sizeof(Intv) + 4) + 3 * (int64_t)(L1 + 2) * sizeof(Intv) + out_cap + post_bytes_per_read(L1, opt) + 64 * 300;
+            if (r1 > r0 + 1 && pr * (int64_t)(r1 - r0 + 1) > budget && ((r1 - r0) & 1) == 0) break;
+            L0 = L1; ++r1;
+        }
+        const int T = (int)(r1 - r0), L = L0;
+        int intv_cap = std::max(64, L + 8) * intv_cap_scale;
+        int attempts = 0;
+        for (;;) {
+            if (++attempts > 8) { fprintf(stderr, "[bwamem_hip] tile could not be sized after 8 attempts\n"); cleanup(); return false; }
+            PE_REQ(ws.ensure_reads(T, L, intv_cap, out_cap, post_bytes_per_read(L, opt)));
+            PE_REQ(ws.ensure_seeds(std::max<int64_t>(ws.seed_cap, (int64_t)T * 16)));
+            TileView tv = ws.view();
+            tv.n_reads = T; tv.max_len = L; tv.read_id0 = read_id0 + r0;
+            tv.seq = b->d_seq.as<uint8_t>(); tv.seq_off = b->d_off.as<int64_t>() + r0;
+            PE_OK(hipMemsetAsync(ws.err.p, 0, 64, ws.stream));
+            PE_OK(hipMemsetAsync(ws.cnt.p, 0, sizeof(DevCounters), ws.stream));
+            TIMED(ws, K_SEED, launch_seed(ws.stream, ix->d, opt, tv));
+            TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_seeds, tv.seed_off, T));
+            int64_t n_occ = 0; int32_t err = 0;
+            PE_OK(hipMemcpyAsync(&n_occ, tv.seed_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
+            PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
+            PE_OK(hipStreamSynchronize(ws.stream));
+            if (err & ERR_INTV_CAP) { intv_cap *= 2; intv_cap_scale *= 2; continue; }
+            if (n_occ > ws.seed_cap) {
+                PE_REQ(ws.ensure_seeds(n_occ + n_occ / 4));
+                TileView t2 = ws.view();
+                t2.n_reads = T; t2.max_len = L; t2.read_id0 = tv.read_id0; t2.seq = tv.seq; t2.seq_off = tv.seq_off;
+                tv = t2;
+            }
+            TIMED(ws, K_SA, launch_sa(ws.stream, ix->d, opt, tv, n_occ));
+            TIMED(ws, K_CHAIN, launch_chain(ws.stream, ix->d, opt, tv, ws.chain_store.as<Chain>()));
+            TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
+            TIMED(ws, K_POST, launch_post1(ws.stream, ix->d, opt, tv));
+            PeTile* pt = new PeTile(); tiles.push_back(pt);
+            pt->r0 = r0; pt->T = T; pt->L = L;
+            PE_REQ(pt->n_regs.ensure((size_t)T * 4) && pt->reg_off.ensure(((size_t)T + 1) * 8));
+            TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_regs, pt->reg_off.as<int64_t>(), T));
+            DevCounters hc;
+            PE_OK(hipMemcpyAsync(&pt->n_regs_total, pt->reg_off.as<int64_t>() + T, 8, hipMemcpyDeviceToHost, ws.stream));
+            PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
+            PE_OK(hipMemcpyAsync(&hc, tv.cnt, sizeof hc, hipMemcpyDeviceToHost, ws.stream));
+            PE_OK(hipStreamSynchronize(ws.stream));
+            if (err) { fprintf(stderr, "[bwamem_hip] device error flags %d in the paired-end phase 1\n", err); cleanup(); return false; }
+            PE_REQ(pt->regs.ensure((size_t)(pt->n_regs_total + 1) * sizeof(AlnReg)));
+            PE_OK(hipMemcpyAsync(pt->n_regs.p, tv.n_regs, (size_t)T * 4, hipMemcpyDeviceToDevice, ws.stream));
+            TIMED(ws, K_OTHER, launch_pe_copy_regs(ws.stream, tv, tv.regs, tv.seed_off, pt->regs.as<AlnReg>(), pt->reg_off.as<int64_t>(), tv.n_regs));
+            if (!pes0) {
+                int np = T >> 1;
+                PE_REQ(d_dir.ensure((size_t)np + 8) && d_is.ensure((size_t)np * 8 + 8));
+                TIMED(ws, K_OTHER, launch_pestat_cand(ws.stream, ix->d, opt, tv, d_dir.as<int8_t>(), d_is.as<int64_t>()));
+                size_t at = cand_dir.size();
+                cand_dir.resize(at + np); cand_is.resize(at + np);
+                if (np) {
+                    PE_OK(hipMemcpyAsync(cand_dir.data() + at, d_dir.p, (size_t)np, hipMemcpyDeviceToHost, ws.stream));
+                    PE_OK(hipMemcpyAsync(cand_is.data() + at, d_is.p, (size_t)np * 8, hipMemcpyDeviceToHost, ws.stream));
+                }
+            }
+            PE_OK(hipStreamSynchronize(ws.stream));
+            {
+                std::lock_guard<std::mutex> lk(g_stats.mu);
+                g_stats.s.n_reads += T; g_stats.s.n_ext += hc.n_ext; g_stats.s.n_lf += hc.n_lf; g_stats.s.n_sa += hc.n_sa;
+                g_stats.s.n_dp_cells += hc.n_dp_cells; ++g_stats.s.n_tiles;
+            }
+            timed_collect(ws);
+            break;
+        }
+        r0 = r1;
+    }
+    // ---------------- insert-size statistics
+    MemPestat pes[4];
+    if (pes0) memcpy(pes, pes0, sizeof pes);
+    else host_pestat(opt, cand_dir, cand_is, pes);
+    // ---------------- phase 2
+    for (PeTile* pt : tiles) {
+        const int T = pt->T, L = pt->L;
+        int attempts = 0, cap_u = 256;
+        for (;;) {
+            if (++attempts > 6) { fprintf(stderr, "[bwamem_hip] paired-end tile could not be sized\n"); cleanup(); return false; }
+            PE_REQ(ws.ensure_reads(T, L, ws.intv_cap ? ws.intv_cap : 64, out_cap, post_bytes_per_read(L, opt)));
+            TileView tv = ws.view();
+            tv.n_reads = T; tv.max_len = L; tv.read_id0 = read_id0 + pt->r0;
+            tv.seq = b->d_seq.as<uint8_t>(); tv.seq_off = b->d_off.as<int64_t>() + pt->r0;
+            PE_OK(hipMemsetAsync(ws.err.p, 0, 64, ws.stream));
+            PE_OK(hipMemcpyAsync(tv.n_regs, pt->n_regs.p, (size_t)T * 4, hipMemcpyDeviceToDevice, ws.stream));
+            PE_REQ(caps.ensure((size_t)T * 4) && reg_off2.ensure(((size_t)T + 1) * 8));
+            TIMED(ws, K_OTHER, launch_pe_caps(ws.stream, opt, tv, caps.as<int32_t>()));
+            TIMED(ws, K_OTHER, launch_scan(ws.stream, caps.as<int32_t>(), reg_off2.as<int64_t>(), T));
+            int64_t tot = 0;
+            PE_OK(hipMemcpyAsync(&tot, reg_off2.as<int64_t>() + T, 8, hipMemcpyDeviceToHost, ws.stream));
+            PE_OK(hipStreamSynchronize(ws.stream));
+            int span = 0;
+            for (int d = 0; d < 4; ++d) if (!pes[d].failed) span = std::max(span, pes[d].high - pes[d].low);
+            const int cap_h = L + 32, cap_b = (span + 2 * L) / 2 + 16;
+            const int64_t per_pair = (((int64_t)16 * cap_h + (int64_t)8 * cap_b + (int64_t)2 * opt.max_matesw * sizeof(AlnReg) + (int64_t)16 * cap_u) + 63) & ~(int64_t)63;
+            PE_REQ(regs2.ensure((size_t)(tot + 1) * sizeof(AlnReg)) && ints2.ensure((size_t)(tot + 1) * 8) && vpool.ensure((size_t)(tot + 2) * 16)
+                   && pe_scratch.ensure((size_t)((T >> 1) + 1) * (size_t)per_pair));
+            TIMED(ws, K_OTHER, launch_pe_copy_regs(ws.stream, tv, pt->regs.as<AlnReg>(), pt->reg_off.as<int64_t>(), regs2.as<AlnReg>(), reg_off2.as<int64_t>(), tv.n_regs));
+            TIMED(ws, K_FINAL, launch_final_pe(ws.stream, ix->d, opt, tv, regs2.as<AlnReg>(), reg_off2.as<int64_t>(), tv.n_regs, ints2.as<int32_t>(), vpool.p,
+                                               pe_scratch.as<uint8_t>(), per_pair, cap_h, cap_b, cap_u, pes));
+            TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.out_len, tv.out_off, T));
+            int64_t out_total = 0; int32_t err = 0;
+            PE_OK(hipMemcpyAsync(&out_total, tv.out_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
+            PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
+            PE_OK(hipStreamSynchronize(ws.stream));
+            if (err & ERR_OUT_CAP) { out_cap *= 4; continue; }
+            if (err & ERR_SCRATCH) { cap_u *= 8; if (attempts < 4) continue; }
+            if (err) { fprintf(stderr, "[bwamem_hip] device error flags %d in the paired-end phase 2\n", err); cleanup(); return false; }
+            TileOut to; to.bytes = (size_t)out_total;
+            if (out_total > 0) {
+                PE_OK(hipMalloc((void**)&to.d, (size_t)out_total));
+                TIMED(ws, K_PACK, launch_pack(ws.stream, tv, to.d));
+                PE_OK(hipStreamSynchronize(ws.stream));
+            }
+            b->tiles.push_back(to);
+            b->result_bytes += to.bytes;
+            timed_collect(ws);
+            break;
+        }
+    }
+    ok = true;
+    cleanup();
+    return ok;
+#undef PE_OK
+#undef PE_REQ
+}
+
 static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, bwamem_batch_s* b, int64_t read_id0)
 {
-    (void)pes;
     HIP_OK(hipSetDevice(ix->device));
     Workspace& ws = ix->ws;
     if (!ws.stream) HIP_OK(hipStreamCreate(&ws.stream));
     for (TileOut& t : b->tiles) if (t.d) (void)hipFree(t.d);
     b->tiles.clear(); b->result_bytes = 0;
-    if (opt.flag & MEM_F_PE) { fprintf(stderr, "[bwamem_hip] paired-end mode (MEM_F_PE) is not implemented on the device path yet\n"); return false; }
     if (b->n_reads == 0) return true;
     HIP_OK(hipMemcpyAsync(b->d_seq.p, b->d_raw.p, b->n_bytes, hipMemcpyDeviceToDevice, ws.stream));
     TIMED(ws, K_ENCODE, launch_encode(ws.stream, b->d_seq.as<uint8_t>(), (int64_t)b->n_bytes));
+    if (opt.flag & MEM_F_PE) return align_batch_pe(ix, opt, pes, b, read_id0);
     const char* env_t = getenv("BWAMEM_HIP_TILE");
     int intv_cap_scale = 1, out_cap = 512;
     int64_t seed_cap_hint = 0;
@@ -281,7 +500,7 @@ static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, b
             HIP_OK(hipMemsetAsync(ws.cnt.p, 0, sizeof(DevCounters), ws.stream));
             TIMED(ws, K_SEED, launch_seed(ws.stream, ix->d, opt, tv));
             TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_seeds, tv.seed_off, T));
-            int64_t n_occ = 0; int32_t err = 0;
+            int64_t n_occ = 0; int32_t err = 0; int32_t errv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             HIP_OK(hipMemcpyAsync(&n_occ, tv.seed_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
             HIP_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
             HIP_OK(hipStreamSynchronize(ws.stream));
@@ -297,6 +516,7 @@ static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, b
             TIMED(ws, K_SA, launch_sa(ws.stream, ix->d, opt, tv, n_occ));
             TIMED(ws, K_CHAIN, launch_chain(ws.stream, ix->d, opt, tv, ws.chain_store.as<Chain>()));
             TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
+            if (getenv("BWAMEM_HIP_DUMP") && T <= 64) debug_dump(ws, tv, T);
             TIMED(ws, K_POST, launch_post1(ws.stream, ix->d, opt, tv));
             TIMED(ws, K_FINAL, launch_final_se(ws.stream, ix->d, opt, tv));
             TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.out_len, tv.out_off, T));
@@ -305,10 +525,12 @@ static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, b
             HIP_OK(hipMemcpyAsync(&out_total, tv.out_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
             HIP_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
             HIP_OK(hipMemcpyAsync(&hc, tv.cnt, sizeof hc, hipMemcpyDeviceToHost, ws.stream));
+            HIP_OK(hipMemcpyAsync(errv, tv.err, sizeof errv, hipMemcpyDeviceToHost, ws.stream));
             HIP_OK(hipStreamSynchronize(ws.stream));
             HIP_OK(hipGetLastError());
             if (err) {
                 { std::lock_guard<std::mutex> lk(g_stats.mu); ++g_stats.s.n_retries; }
+                if (err & ERR_BAD_REG) { fprintf(stderr, "[bwamem_hip] internal error: extension produced an invalid region (tile read %d of call read %lld: n=%d qb=%d qe=%d rb=%d re=%d score=%d)\n", errv[1], (long long)(read_id0 + r0 + errv[1]), errv[2], errv[3], errv[4], errv[5], errv[6], errv[7]); return false; }
                 if (err & ERR_LONG_READ) { fprintf(stderr, "[bwamem_hip] reads long enough to need seed re-scoring (mem_flt_chained_seeds) are not supported on the device path yet\n"); return false; }
                 if (err & ERR_BTREE) { fprintf(stderr, "[bwamem_hip] internal error: chain B-tree pool exhausted\n"); return false; }
                 if (err & (ERR_SCRATCH | ERR_CIGAR_CAP)) { fprintf(stderr, "[bwamem_hip] internal error: post-processing scratch exhausted (err=%d)\n", err); return false; }

@@ -298,6 +298,81 @@ DEV AlnRec reg2aln(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int l_
     return a;
 }
 
+// ------------------------------------------------------------------ sort comparators
+struct RegReLt { __device__ bool operator()(const AlnReg& a, const AlnReg& b) const { return a.re < b.re; } };
+struct RegSLt  { __device__ bool operator()(const AlnReg& a, const AlnReg& b) const {
+    return a.score > b.score || (a.score == b.score && (a.rb < b.rb || (a.rb == b.rb && a.qb < b.qb))); } };
+
+// mem_patch_reg: can two colinear regions be merged into one global alignment?
+DEV int patch_reg(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const uint8_t* query, const AlnReg& a, const AlnReg& b, int* _w)
+{
+    if (a.rb < ix.l_pac && b.rb >= ix.l_pac) return 0;
+    if (a.qb >= b.qb || a.qe >= b.qe || a.re >= b.re) return 0;
+    int w = (int)((a.re - b.rb) - (a.qe - b.qb));
+    w = w > 0 ? w : -w;
+    double r = (double)(a.re - b.rb) / (b.re - a.rb) - (double)(a.qe - b.qb) / (b.qe - a.qb);
+    r = r > 0. ? r : -r;
+    if (a.re < b.rb || a.qe < b.qb) {
+        if (w > opt.w << 1 || r >= 0.05f) return 0;
+    } else if (w > opt.w << 2 || r >= 0.05f * 2) return 0;
+    w += a.w + b.w;
+    w = w < opt.w << 2 ? w : opt.w << 2;
+    int score = 0;
+    gen_cigar2(ix, opt, S, w, b.qe - a.qb, query + a.qb, a.rb, b.re, &score, false, 0, 0);
+    int q_s = (int)((double)(b.qe - a.qb) / ((b.qe - b.qb) + (a.qe - a.qb)) * (b.score + a.score) + .499);
+    int r_s = (int)((double)(b.re - a.rb) / ((b.re - b.rb) + (a.re - a.rb)) * (b.score + a.score) + .499);
+    if ((double)score / (q_s > r_s ? q_s : r_s) < 0.90f) return 0;
+    *_w = w;
+    return score;
+}
+
+// mem_sort_dedup_patch; query == 0 disables patching (the mate-rescue caller)
+DEV int sort_dedup_patch(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const uint8_t* query, int n, AlnReg* a)
+{
+    int m, i, j;
+    if (n <= 1) return n;
+    ks_introsort((size_t)n, a, RegReLt());
+    for (i = 0; i < n; ++i) a[i].n_comp = 1;
+    for (i = 1; i < n; ++i) {
+        AlnReg* p = &a[i];
+        if (p->rid != a[i - 1].rid || p->rb >= a[i - 1].re + opt.max_chain_gap) continue;
+        for (j = i - 1; j >= 0 && p->rid == a[j].rid && p->rb < a[j].re + opt.max_chain_gap; --j) {
+            AlnReg* q = &a[j];
+            int64_t orr, oq, mr, mq;
+            int score, w;
+            if (q->qe == q->qb) continue;
+            orr = q->re - p->rb;
+            oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
+            mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
+            mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
+            if ((float)orr > opt.mask_level_redun * (float)mr && (float)oq > opt.mask_level_redun * (float)mq) {
+                if (p->score < q->score) { p->qe = p->qb; break; }
+                else q->qe = q->qb;
+            } else if (query && q->rb < p->rb && (score = patch_reg(ix, opt, S, query, *q, *p, &w)) > 0) {
+                p->n_comp += q->n_comp + 1;
+                p->seedcov = p->seedcov > q->seedcov ? p->seedcov : q->seedcov;
+                p->sub = p->sub > q->sub ? p->sub : q->sub;
+                p->csub = p->csub > q->csub ? p->csub : q->csub;
+                p->qb = q->qb; p->rb = q->rb;
+                p->truesc = p->score = score;
+                p->w = w;
+                q->qb = q->qe;
+            }
+        }
+    }
+    for (i = 0, m = 0; i < n; ++i)
+        if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
+    n = m;
+    ks_introsort((size_t)n, a, RegSLt());
+    for (i = 1; i < n; ++i)
+        if (a[i].score == a[i - 1].score && a[i].rb == a[i - 1].rb && a[i].qb == a[i - 1].qb)
+            a[i].qe = a[i].qb;
+    for (i = 1, m = 1; i < n; ++i)
+        if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
+    return m;
+}
+
+
 // ------------------------------------------------------------------ primary marking (a14)
 struct RegHLt  { __device__ bool operator()(const AlnReg& a, const AlnReg& b) const {
     return a.score > b.score || (a.score == b.score && (a.is_alt < b.is_alt || (a.is_alt == b.is_alt && a.hash < b.hash))); } };

@@ -39,3 +39,19 @@ def test_emu_small_genome(emu, oracle, small_genome):
     reads += B.simulate_reads(seqs, 8, length=251, seed=3, sub=0.05, indel=0.01)
     _cmp(emu, oracle, img, reads)
     _cmp(emu, oracle, img, reads[:12], flag=B.MEM_F_ALL, w=10, T=20)
+
+
+def test_emu_paired_end(emu, oracle, rota_img, small_genome):
+    pr = [b"GGCTTTTAATGCTTTTCAGTGGTTGCTGCTCAAGATGGAGTCTACTCAGCAGATGGTAAGCTCTATTATT",
+          b"TTGTTTTTAACACCAGAGTCATCCATCACATAATCAAATTTACTTTTAACTCTGGTAAATACTTCATTGT"]
+    seqs, img = small_genome
+    pairs = B.simulate_pairs(seqs, 12, length=100, seed=5, ins_mean=300, ins_sd=30)
+    pairs[3] = bytes(c if i % 7 else 65 for i, c in enumerate(pairs[3]))      # a mate that needs rescue
+    for image, reads, stats in [(rota_img, pr, [None, B.pack_pestat(1, 600, 200.0, 10.0), B.pack_pestat(0, 0, 0, 0, failed=True)]),
+                                (img, pairs, [None, B.pack_pestat(150, 450, 300.0, 30.0)])]:
+        h, ho = emu.open_index(image), oracle.open_index(image)
+        for pes in stats:
+            opts = B.set_opt(emu.default_options(), flag=B.MEM_F_PE)
+            req = B.pack_request(reads)
+            assert emu.align_raw(h, opts, req, pes) == oracle.align_raw(ho, opts, req, pes)
+        emu.destroy_index(h); oracle.destroy_index(ho)

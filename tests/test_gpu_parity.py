@@ -143,3 +143,80 @@ def test_parity_medium_genome(hip_lib, oracle, medium_genome):
     seqs, img = medium_genome
     reads = B.simulate_reads(seqs, 20000, length=150, seed=42)
     _parity(hip_lib, oracle, img, reads)
+
+
+# ---------------------------------------------------------------- paired-end
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_pair(bwamem, rota_index, mode):          # BwaMemIndexTest.testPair x3
+    seqs = ["GGCTTTTAATGCTTTTCAGTGGTTGCTGCTCAAGATGGAGTCTACTCAGCAGATGGTAAGCTCTATTATT",
+            "TTGTTTTTAACACCAGAGTCATCCATCACATAATCAAATTTACTTTTAACTCTGGTAAATACTTCATTGT"]
+    aligner = bwamem.BwaMemAligner(rota_index)
+    aligner.alignPairs()
+    if mode == 1:
+        aligner.setProperPairEndStats(bwamem.BwaMemPairEndStats(200, 10, 1, 600))
+    elif mode == 2:
+        aligner.dontInferPairEndStats()
+    else:
+        aligner.inferPairEndStats()
+    alignments = aligner.alignSeqs(seqs)
+    assert [len(a) for a in alignments] == [1, 1]
+    a0, a1 = alignments[0][0], alignments[1][0]
+    check(a0, 0, 70, 0, 70, "70M", 0, 0x63 if mode == 1 else 0x61)
+    assert a0.getMateRefStart() == 140 and a0.getTemplateLen() == 210
+    check(a1, 140, 210, 0, 70, "70M", 0, 0x93 if mode == 1 else 0x91)
+    assert a1.getMateRefStart() == 0 and a1.getTemplateLen() == -210
+
+
+def _parity_pe(hip, orc, img, reads, pes=None, **optkw):
+    h, ho = hip.open_index(img), orc.open_index(img)
+    try:
+        opts = B.set_opt(hip.default_options(), flag=B.MEM_F_PE | optkw.pop("flag", 0), **optkw)
+        req = B.pack_request(reads)
+        got = hip.align_raw(h, opts, req, pes)
+        want = orc.align_raw(ho, opts, req, pes)
+        assert got is not None
+        if got != want:
+            sa, sb = B.split_response(got, len(reads)), B.split_response(want, len(reads))
+            bad = [i for i in range(len(reads)) if sa[i] != sb[i]]
+            pytest.fail("%d/%d PE reads differ; first: read %d\n  hip    %r\n  oracle %r" % (
+                len(bad), len(reads), bad[0], B.decode_response(sa[bad[0]], 1), B.decode_response(sb[bad[0]], 1)))
+        return got
+    finally:
+        hip.destroy_index(h); orc.destroy_index(ho)
+
+
+def _damaged_pairs(seqs, n, seed):
+    import random
+    pairs = B.simulate_pairs(seqs, n, length=100, seed=seed, ins_mean=300, ins_sd=30, sub=0.01)
+    rnd = random.Random(seed)
+    for i in range(1, len(pairs), 6):                 # some mates too diverged to seed: mate rescue has to find them
+        r = bytearray(pairs[i])
+        for k in range(0, len(r), 7):
+            r[k] = ord("ACGT"[rnd.randrange(4)])
+        pairs[i] = bytes(r)
+    for i in range(0, len(pairs), 50):                # some junk mates
+        pairs[i] = bytes(ord("ACGT"[rnd.randrange(4)]) for _ in range(100))
+    return pairs
+
+
+def test_parity_pe_inferred_stats(hip_lib, oracle, small_genome):
+    seqs, img = small_genome
+    _parity_pe(hip_lib, oracle, img, _damaged_pairs(seqs, 1500, 5))
+
+
+def test_parity_pe_given_stats_and_flags(hip_lib, oracle, small_genome):
+    seqs, img = small_genome
+    pairs = _damaged_pairs(seqs, 600, 6)
+    _parity_pe(hip_lib, oracle, img, pairs, pes=B.pack_pestat(150, 450, 300.0, 30.0))
+    _parity_pe(hip_lib, oracle, img, pairs, pes=B.pack_pestat(0, 0, 0, 0, failed=True))
+    _parity_pe(hip_lib, oracle, img, pairs, flag=B.MEM_F_NO_RESCUE)
+    _parity_pe(hip_lib, oracle, img, pairs, flag=B.MEM_F_NOPAIRING)
+    _parity_pe(hip_lib, oracle, img, pairs[:-1])       # odd read count: the unpaired tail produces no bytes
+
+
+def test_pe_multi_tile(hip_lib, oracle, small_genome, monkeypatch):
+    seqs, img = small_genome
+    pairs = _damaged_pairs(seqs, 400, 7)
+    whole = _parity_pe(hip_lib, oracle, img, pairs)
+    monkeypatch.setenv("BWAMEM_HIP_TILE", "90")
+    assert _parity_pe(hip_lib, oracle, img, pairs) == whole
