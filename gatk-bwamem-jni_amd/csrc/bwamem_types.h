@@ -141,4 +141,6 @@ struct TileView {
     // flags + counters
     int32_t* err;
     DevCounters* cnt;
+    int32_t debug;                // BWAMEM_HIP_DEBUGK: device-side progress prints (debugging aid)
+    int32_t pad_;
 };

@@ -207,12 +207,16 @@ DEV void ks_combsort(size_t n, T* a, LT lt)
     if (gap != 1) ks_insertsort(a, a + n, lt);
 }
 
+// NB: the partition scans are written with explicit bounds and the pivot is read through a pointer.
+// hipcc -O3 (ROCm 7.2, gfx950) miscompiles the upstream-style sentinel scans
+// "do ++i; while (lt(*i, rp));" into a non-terminating loop (tests/gpu_units/sort_unit.hip);
+// the decisions taken are identical because a[t] == pivot stops the scan at t at the latest.
 template <typename T, typename LT>
 DEV void ks_introsort(size_t n, T* a, LT lt)
 {
     struct Frame { T* left; T* right; int depth; };
     Frame stack[66];
-    Frame* top = stack;
+    int sp = 0;
     if (n < 1) return;
     if (n == 2) {
         if (lt(a[1], a[0])) { T tmp = a[0]; a[0] = a[1]; a[1] = tmp; }
@@ -220,34 +224,39 @@ DEV void ks_introsort(size_t n, T* a, LT lt)
     }
     int d;
     for (d = 2; 1ul << d < n; ++d);
-    T *s = a, *t = a + (n - 1), *i, *j, *k;
+    T *s = a, *t = a + (n - 1);
     d <<= 1;
-    for (;;) {
+    bool done = false;
+    while (!done) {
         if (s < t) {
-            if (--d == 0) { ks_combsort((size_t)(t - s + 1), s, lt); t = s; continue; }
-            i = s; j = t; k = i + ((j - i) >> 1) + 1;
-            if (lt(*k, *i)) { if (lt(*k, *j)) k = j; }
-            else k = lt(*j, *i) ? i : j;
-            T rp = *k;
-            if (k != t) { T tmp = *k; *k = *t; *t = tmp; }
-            for (;;) {
-                do ++i; while (lt(*i, rp));
-                do --j; while (i <= j && lt(rp, *j));
-                if (j <= i) break;
-                T tmp = *i; *i = *j; *j = tmp;
+            --d;
+            if (d == 0) { ks_combsort((size_t)(t - s + 1), s, lt); t = s; }
+            else {
+                T *i = s, *j = t, *k = i + ((j - i) >> 1) + 1;
+                if (lt(*k, *i)) { if (lt(*k, *j)) k = j; }
+                else k = lt(*j, *i) ? i : j;
+                if (k != t) { T tmp = *k; *k = *t; *t = tmp; }
+                const T* rp = t;                      // the pivot now sits at t and is not moved by the scans
+                bool more = true;
+                while (more) {
+                    ++i; while (i < t && lt(*i, *rp)) ++i;
+                    --j; while (i <= j && lt(*rp, *j)) --j;
+                    if (j <= i) more = false;
+                    else { T tmp = *i; *i = *j; *j = tmp; }
+                }
+                { T tmp = *i; *i = *t; *t = tmp; }
+                if (i - s > t - i) {
+                    if (i - s > 16) { stack[sp].left = s; stack[sp].right = i - 1; stack[sp].depth = d; ++sp; }
+                    s = t - i > 16 ? i + 1 : t;
+                } else {
+                    if (t - i > 16) { stack[sp].left = i + 1; stack[sp].right = t; stack[sp].depth = d; ++sp; }
+                    t = i - s > 16 ? i - 1 : s;
+                }
             }
-            { T tmp = *i; *i = *t; *t = tmp; }
-            if (i - s > t - i) {
-                if (i - s > 16) { top->left = s; top->right = i - 1; top->depth = d; ++top; }
-                s = t - i > 16 ? i + 1 : t;
-            } else {
-                if (t - i > 16) { top->left = i + 1; top->right = t; top->depth = d; ++top; }
-                t = i - s > 16 ? i - 1 : s;
-            }
-        } else {
-            if (top == stack) { ks_insertsort(a, a + n, lt); return; }
-            --top; s = top->left; t = top->right; d = top->depth;
-        }
+        } else if (sp == 0) {
+            ks_insertsort(a, a + n, lt);
+            done = true;
+        } else { --sp; s = stack[sp].left; t = stack[sp].right; d = stack[sp].depth; }
     }
 }
 

@@ -98,6 +98,7 @@ struct Workspace {
         tv.out_cap = out_cap; tv.out = out.as<uint8_t>(); tv.out_len = out_len.as<int32_t>(); tv.out_off = out_off.as<int64_t>();
         tv.post_scratch = post.as<uint8_t>(); tv.post_scratch_per_read = post_per_read;
         tv.err = err.as<int32_t>(); tv.cnt = cnt.as<DevCounters>();
+        { const char* e = getenv("BWAMEM_HIP_DEBUGK"); tv.debug = e ? atoi(e) : 0; }
         return tv;
     }
 };

@@ -327,11 +327,13 @@ DEV int patch_reg(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const u
 }
 
 // mem_sort_dedup_patch; query == 0 disables patching (the mate-rescue caller)
-DEV int sort_dedup_patch(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const uint8_t* query, int n, AlnReg* a)
+DEV int sort_dedup_patch(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const uint8_t* query, int n, AlnReg* a, int dbg = 0)
 {
     int m, i, j;
     if (n <= 1) return n;
+    if (dbg) printf("[k] sdp: n=%d before sort1\n", n);
     ks_introsort((size_t)n, a, RegReLt());
+    if (dbg) printf("[k] sdp: after sort1: re %lld %lld\n", (long long)a[0].re, (long long)a[1].re);
     for (i = 0; i < n; ++i) a[i].n_comp = 1;
     for (i = 1; i < n; ++i) {
         AlnReg* p = &a[i];
@@ -363,7 +365,9 @@ DEV int sort_dedup_patch(const DevIndex& ix, const MemOpt& opt, PostScratch& S, 
     for (i = 0, m = 0; i < n; ++i)
         if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
     n = m;
+    if (dbg) printf("[k] sdp: before sort2 n=%d\n", n);
     ks_introsort((size_t)n, a, RegSLt());
+    if (dbg) printf("[k] sdp: after sort2\n");
     for (i = 1; i < n; ++i)
         if (a[i].score == a[i - 1].score && a[i].rb == a[i - 1].rb && a[i].qb == a[i - 1].qb)
             a[i].qe = a[i].qb;

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <functional>
+#include <stdio.h>
 
 #define __global__
 #define __device__
