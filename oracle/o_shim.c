@@ -230,3 +230,9 @@ void *oracle_createAlignments(o_idx_t *idx, o_opt_t *opt, o_pestat_t *pes0, char
 	*pBufSize = tot;
 	return res;
 }
+
+/* ---- test hooks: expose the order-exact sort on (x, y) pairs compared by x only, so the tie permutation is observable ---- */
+typedef struct { uint64_t x, y; } o_pairx_t;
+#define pairx_lt(a, b) ((a).x < (b).x)
+O_SORT_DECL(pairx, o_pairx_t, pairx_lt)
+void oracle_test_sort_pairs(size_t n, uint64_t *xy) { o_introsort_pairx(n, (o_pairx_t*)xy); }

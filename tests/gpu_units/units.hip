@@ -1,0 +1,67 @@
+// tests/gpu_units/units.hip -- TEST INFRASTRUCTURE: thin host-callable wrappers that run single device
+// functions of the product (introsort, the wave-parallel extension DP, rank queries) on caller-supplied
+// inputs, so tests can compare them with the oracle one function at a time.  Built by the test fixtures
+// (hipcc on the GPU box, the emulation build on CPU); never part of libbwamem_hip.so.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+#include "../../gatk-bwamem-jni_amd/csrc/k_extend.hip"
+
+struct PairX { uint64_t x, y; };
+struct PairXLt { __device__ bool operator()(const PairX& a, const PairX& b) const { return a.x < b.x; } };
+
+__global__ void k_unit_sort_pairs(PairX* a, int n) { if (threadIdx.x == 0 && blockIdx.x == 0) ks_introsort((size_t)n, a, PairXLt()); }
+
+__global__ void __launch_bounds__(64) k_unit_extend(DevIndex ix, MemOpt opt, const uint8_t* query, int qlen, int tlen, int w, int end_bonus, int zdrop, int h0, int* out)
+{
+    HIP_DYNAMIC_SHARED(int32_t, smem)
+    const int cap = qlen + 2, lane = threadIdx.x;
+    ExtLds L;
+    L.eh_h = smem; L.eh_e = smem + cap; L.tmpM = smem + 2 * cap;
+    uint8_t* sq = (uint8_t*)(smem + 3 * cap);
+    L.query = sq;
+    for (int j = lane; j < qlen; j += WAVE) sq[j] = query[j];
+    __syncthreads();
+    unsigned long long n_cells = 0;
+    ExtRes r = extend_wave(ix, opt, L, lane, qlen, 0, 1, tlen, 0, 1, w, end_bonus, zdrop, h0, n_cells);
+    if (lane == 0) { out[0] = r.score; out[1] = r.qle; out[2] = r.tle; out[3] = r.gtle; out[4] = r.gscore; out[5] = r.max_off; }
+}
+
+__global__ void k_unit_occ(DevIndex ix, const uint64_t* ks, int n, uint64_t* out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { uint64_t c[4]; occ4(ix, ks[i], c); for (int j = 0; j < 4; ++j) out[4 * i + j] = c[j]; }
+}
+
+extern "C" int unit_sort_pairs(int n, uint64_t* xy)
+{
+    PairX* d;
+    if (hipMalloc((void**)&d, (size_t)n * 16 + 16) != hipSuccess) return -1;
+    hipMemcpy(d, xy, (size_t)n * 16, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_unit_sort_pairs, dim3(1), dim3(64), 0, 0, d, n);
+    int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+    hipMemcpy(xy, d, (size_t)n * 16, hipMemcpyDeviceToHost);
+    hipFree(d);
+    return rc;
+}
+
+// target is packed 2 bit/base into a throw-away "reference" so extend_wave reads it exactly as in production
+extern "C" int unit_extend(const uint8_t* query, int qlen, const uint8_t* target, int tlen, const MemOpt* opt,
+                           int w, int end_bonus, int zdrop, int h0, int* out6)
+{
+    std::vector<uint8_t> pac((size_t)tlen / 4 + 2, 0);
+    for (int i = 0; i < tlen; ++i) pac[i >> 2] |= (uint8_t)(target[i] << ((~i & 3) << 1));
+    uint8_t *d_pac, *d_q; int* d_out;
+    hipMalloc((void**)&d_pac, pac.size()); hipMalloc((void**)&d_q, (size_t)qlen + 16); hipMalloc((void**)&d_out, 64);
+    hipMemcpy(d_pac, pac.data(), pac.size(), hipMemcpyHostToDevice);
+    hipMemcpy(d_q, query, (size_t)qlen, hipMemcpyHostToDevice);
+    DevIndex ix; memset(&ix, 0, sizeof ix);
+    ix.pac = d_pac; ix.l_pac = tlen;
+    size_t cap = (size_t)qlen + 2, shmem = 3 * cap * 4 + ((cap + 15) & ~(size_t)15);
+    hipLaunchKernelGGL(k_unit_extend, dim3(1), dim3(64), shmem, 0, ix, *opt, d_q, qlen, tlen, w, end_bonus, zdrop, h0, d_out);
+    int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+    hipMemcpy(out6, d_out, 24, hipMemcpyDeviceToHost);
+    hipFree(d_pac); hipFree(d_q); hipFree(d_out);
+    return rc;
+}

@@ -1,0 +1,95 @@
+"""Function-level parity: single device functions of the product (wrapped by tests/gpu_units/units.hip)
+against the oracle's counterparts on random inputs.  The emulation flavour runs in the CPU suite;
+the hipcc flavour is the GPU test (it is what caught the hipcc -O3 introsort miscompile)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import bwalib as B
+
+UNITS = os.path.join(B.ROOT, "tests", "gpu_units")
+
+
+def _load(flavour):
+    subprocess.run(["make", "-s", "-C", UNITS] + (["emu"] if flavour == "emu" else []), check=True)
+    lib = ctypes.CDLL(os.path.join(UNITS, "_build", "libunits_%s.so" % flavour))
+    lib.unit_sort_pairs.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    lib.unit_extend.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    return lib
+
+
+def _sort_cases(rng, sizes, n_keys):
+    for n in sizes:
+        for k in n_keys:
+            x = rng.integers(0, k, size=n, dtype=np.uint64)
+            yield np.stack([x, np.arange(n, dtype=np.uint64)], axis=1).copy()
+    # adversarial shapes: sorted, reversed, all equal, organ pipe
+    for n in (3, 17, 40, 200):
+        a = np.arange(n, dtype=np.uint64)
+        for x in (a, a[::-1].copy(), np.zeros(n, dtype=np.uint64), np.minimum(a, a[::-1])):
+            yield np.stack([x, np.arange(n, dtype=np.uint64)], axis=1).copy()
+
+
+def _check_sort(units, oracle, sizes):
+    osort = oracle.dll.oracle_test_sort_pairs
+    osort.argtypes = [ctypes.c_size_t, ctypes.c_void_p]
+    rng = np.random.default_rng(3)
+    for xy in _sort_cases(rng, sizes, (2, 5, 1000)):
+        want = xy.copy(); osort(len(want), want.ctypes.data)
+        got = xy.copy(); assert units.unit_sort_pairs(len(got), got.ctypes.data) == 0
+        assert (got == want).all(), "tie permutation differs for n=%d" % len(xy)
+
+
+def _check_extend(units, oracle, n_cases, max_q):
+    oext = oracle.dll.o_ksw_extend2
+    oext.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p] * 5
+    rng = np.random.default_rng(11)
+    base_opts = oracle.default_options()
+    for it in range(n_cases):
+        qlen = int(rng.integers(1, max_q)); tlen = int(rng.integers(1, max_q + 60))
+        t = rng.integers(0, 4, size=tlen, dtype=np.uint8)
+        # query = mutated copy of the target so that the DP actually extends
+        q = np.resize(t, qlen).copy()
+        mut = rng.random(qlen) < rng.choice([0.0, 0.02, 0.1, 0.4])
+        q[mut] = rng.integers(0, 5, size=int(mut.sum()), dtype=np.uint8)
+        if rng.random() < 0.4 and qlen > 12:                       # an indel
+            cut = int(rng.integers(3, qlen - 3)); k = int(rng.integers(1, 8))
+            q = np.concatenate([q[:cut], q[cut + k:]]) if rng.random() < 0.5 else np.concatenate([q[:cut], rng.integers(0, 4, size=k, dtype=np.uint8), q[cut:]])
+            qlen = len(q)
+        kw = dict(a=int(rng.choice([1, 2])), b=int(rng.choice([4, 9, 2])), o_del=int(rng.choice([6, 16, 0])), e_del=int(rng.choice([1, 2])),
+                  o_ins=int(rng.choice([6, 16, 0])), e_ins=int(rng.choice([1, 3])))
+        opts = B.set_opt(bytearray(base_opts), **kw)
+        mat = []
+        for i in range(4):
+            mat += [kw["a"] if i == j else -kw["b"] for j in range(4)] + [-1]
+        mat += [-1] * 5
+        B.set_opt(opts, mat=mat)
+        w = int(rng.choice([100, 200, 5, 1])); zdrop = int(rng.choice([100, 0, 10])); end_bonus = int(rng.choice([5, 0])); h0 = int(rng.integers(0, 150))
+        want = (ctypes.c_int * 5)()
+        ws = oext(qlen, q.tobytes(), tlen, t.tobytes(), 5, bytes(opts[140:165]), kw["o_del"], kw["e_del"], kw["o_ins"], kw["e_ins"], w, end_bonus, zdrop, h0,
+                  ctypes.byref(want, 0), ctypes.byref(want, 4), ctypes.byref(want, 8), ctypes.byref(want, 12), ctypes.byref(want, 16))
+        got = (ctypes.c_int * 6)()
+        ob = ctypes.create_string_buffer(bytes(opts), 168)
+        assert units.unit_extend(q.tobytes(), qlen, t.tobytes(), tlen, ob, w, end_bonus, zdrop, h0, got) == 0
+        assert list(got) == [ws, want[0], want[1], want[2], want[3], want[4]], (it, qlen, tlen, kw, w, zdrop, h0)
+
+
+def test_units_emu_sort(oracle):
+    _check_sort(_load("emu"), oracle, (2, 3, 4, 9, 16, 17, 18, 33, 100, 600))
+
+
+def test_units_emu_extend(oracle):
+    _check_extend(_load("emu"), oracle, 40, 150)
+
+
+@pytest.mark.gpu
+def test_units_gpu_sort(oracle):
+    _check_sort(_load("hip"), oracle, (2, 3, 4, 9, 16, 17, 18, 33, 100, 600, 5000))
+
+
+@pytest.mark.gpu
+def test_units_gpu_extend(oracle):
+    _check_extend(_load("hip"), oracle, 1500, 300)
