@@ -237,7 +237,8 @@ def main():
         orc = B.oracle_lib()
         S = min(args.cpu_sample, R)
         req = struct.pack("<i", S) + payload[:S].cpu().numpy().tobytes()
-        cores = os.cpu_count() or 1
+        # the GPU box hands one GPU's share of the host to this process (16 cores); stay inside it
+        cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
         ho = orc.open_index(img)
         oo = B.set_opt(orc.default_options(), n_threads=cores)
         tc = time.time()
