@@ -62,7 +62,10 @@ def synth_genome(torch, dev, total_bp, n_contigs, seed):
     w = torch.rand(n_contigs, generator=g, device=dev) + 0.5
     lens = (w / w.sum() * total_bp).long()
     lens[-1] += total_bp - int(lens.sum())
-    codes = torch.randint(0, 4, (total_bp,), dtype=torch.uint8, generator=g, device=dev)
+    codes = torch.empty(total_bp, dtype=torch.uint8, device=dev)
+    for lo in range(0, total_bp, 1 << 30):                       # some torch ops are limited to < 2^31 elements per call
+        hi = min(total_bp, lo + (1 << 30))
+        codes[lo:hi] = torch.randint(0, 4, (hi - lo,), dtype=torch.uint8, generator=g, device=dev)
     n_rep = int(0.05 * total_bp)
     hg = torch.Generator(); hg.manual_seed(seed + 1)
     done = 0
@@ -152,22 +155,30 @@ def main():
     if args.image:
         img = args.image
         raise SystemExit("--image needs the packed reference to sample reads from; not wired yet")
+    def note(msg):
+        if rank == 0:
+            print("[bench] %6.1fs %s" % (time.time() - t0, msg), file=sys.stderr, flush=True)
     codes, contigs = synth_genome(torch, dev, args.genome_bp, args.contigs, 0x5EED)
+    note("synthetic genome ready")
     import index_build_gpu as G
     pieces = G.build_pieces(codes)
+    note("suffix array / BWT / occ / SA built on the device")
     tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
     img = os.path.join(tmpdir, "bwamem_hip_bench_%d_%d.img" % (os.getpid(), rank))
     G.write_image(img, pieces, contigs)
     del pieces
     torch.cuda.empty_cache()
     t_index = time.time() - t0
+    note("index image written (%.2f GB)" % (os.path.getsize(img) / 1e9))
     idx = lib.jnibwa_openIndex(os.open(img, os.O_RDONLY))
+    note("index resident in HBM")
     if not idx:
         raise SystemExit("openIndex failed")
 
     # ---- request resident in HBM (not timed)
     L, R = args.read_len, args.reads
     payload = synth_reads(torch, dev, codes, contigs, R, L, 42 + rank)
+    note("%d reads generated on the device" % R)
     del codes
     torch.cuda.empty_cache()
     h_off = (np.arange(R + 1, dtype=np.int64) * (L + 1))

@@ -17,6 +17,27 @@ import numpy as np
 import torch
 
 SIGN = -(1 << 63)
+CHUNK = 1 << 30          # several torch ops (nonzero, flip) are limited to < 2^31 elements per call
+
+
+def _nonzero_chunked(mask_fn, n, device):
+    """indices i in [0, n) with mask_fn(lo, hi)[i - lo] true, evaluated CHUNK elements at a time"""
+    out = []
+    for lo in range(0, n, CHUNK):
+        hi = min(n, lo + CHUNK)
+        idx = torch.nonzero(mask_fn(lo, hi)).squeeze(1)
+        if idx.numel():
+            out.append(idx + lo)
+    return torch.cat(out) if out else torch.zeros(0, dtype=torch.int64, device=device)
+
+
+def _revcomp(fwd):
+    n = fwd.numel()
+    out = torch.empty_like(fwd)
+    for lo in range(0, n, CHUNK):
+        hi = min(n, lo + CHUNK)
+        out[n - hi: n - lo] = 3 - torch.flip(fwd[lo:hi], [0])
+    return out
 
 
 def _pack_words(T, n_words, chunk=1 << 26):
@@ -110,36 +131,48 @@ def suffix_array(T):
     dev = T.device
     n = T.numel()
     W = _pack_words(T, (n + 31) // 32 + 4)
-    nxt = torch.zeros_like(T)
-    nxt[:-1] = T[1:]
-    code = T * 4 + nxt
-    del nxt
-    out = []
+    code = torch.empty_like(T)
+    for lo in range(0, n, CHUNK):
+        hi = min(n, lo + CHUNK)
+        nxt = torch.zeros(hi - lo, dtype=torch.uint8, device=dev)
+        m = min(n, hi + 1) - (lo + 1)
+        nxt[:m] = T[lo + 1: lo + 1 + m]
+        code[lo:hi] = T[lo:hi] * 4 + nxt
+    sa = torch.empty(n, dtype=torch.int64, device=dev)
+    at = 0
     for b in range(16):
-        pos = torch.nonzero(code == b).squeeze(1)
-        out.append(_sort_bucket(W, pos, n, 2) if pos.numel() else pos)
+        pos = _nonzero_chunked(lambda lo, hi: code[lo:hi] == b, n, dev)
+        if pos.numel():
+            sa[at: at + pos.numel()] = _sort_bucket(W, pos, n, 2)
+            at += pos.numel()
+        del pos
     del code
-    return torch.cat(out)
+    return sa
 
 
 def build_pieces(fwd):
     """fwd: uint8 tensor of base codes (no ambiguous bases left).  Returns dict of numpy pieces."""
     dev = fwd.device
     l_pac = fwd.numel()
-    T = torch.cat([fwd, 3 - torch.flip(fwd, [0])])
+    T = torch.empty(2 * l_pac, dtype=torch.uint8, device=dev)
+    T[:l_pac] = fwd
+    T[l_pac:] = _revcomp(fwd)
     n = T.numel()
     sa = suffix_array(T)
     # sentinel-inclusive ranks: rank 0 = empty suffix; rank k = sa[k-1]
-    zero_at = int(torch.nonzero(sa == 0)[0, 0])
+    zero_at = int(_nonzero_chunked(lambda lo, hi: sa[lo:hi] == 0, n, dev)[0])
     primary = zero_at + 1
-    # BWT without the sentinel position
-    src = torch.cat([sa[:zero_at], sa[zero_at + 1:]]) - 1
-    B = torch.empty(n, dtype=torch.uint8, device=dev)
-    B[0] = T[n - 1]                                        # rank 0: the symbol before the sentinel
+    # BWT without the sentinel position: ranks 0..n with rank `primary` left out
     step = 1 << 28
-    for i in range(0, n - 1, step):
-        B[1 + i: 1 + min(n - 1, i + step)] = T[src[i: i + step]]
-    del src
+    Bfull = torch.empty(n + 1, dtype=torch.uint8, device=dev)
+    Bfull[0] = T[n - 1]                                    # rank 0: the symbol before the sentinel
+    for i in range(0, n, step):
+        j = min(n, i + step)
+        Bfull[1 + i: 1 + j] = T[torch.clamp(sa[i:j] - 1, min=0)]
+    B = torch.empty(n, dtype=torch.uint8, device=dev)
+    B[:primary] = Bfull[:primary]
+    B[primary:] = Bfull[primary + 1:]
+    del Bfull
     counts = torch.zeros(4, dtype=torch.int64, device=dev)
     for i in range(0, n, step):
         counts += torch.bincount(T[i: i + step].to(torch.int64), minlength=4)[:4]
@@ -149,7 +182,11 @@ def build_pieces(fwd):
     # interleaved occ + bwt words
     nblk = (n + 127) // 128
     pad = nblk * 128 - n
-    Bp = torch.cat([B, torch.zeros(pad, dtype=torch.uint8, device=dev)]) if pad else B
+    if pad:
+        Bp = torch.zeros(nblk * 128, dtype=torch.uint8, device=dev)
+        Bp[:n] = B
+    else:
+        Bp = B
     blk = torch.zeros((nblk, 16), dtype=torch.int32, device=dev)
     tot = []
     for c in range(4):
