@@ -114,7 +114,7 @@ struct TileView {
     int32_t intv_cap;             // per-read capacity of intv / scratch vectors
     Intv* intv;                   // [n_reads][intv_cap]
     int32_t* n_intv;              // [n_reads]
-    Intv* smem_scratch;           // [n_reads][3][smem_cap]  (mem1, prev, curr)
+    Intv* smem_scratch;           // [n_reads/64][2][smem_cap][64 lanes]  (prev, curr), lane-interleaved
     int32_t smem_cap;
     int32_t* l_rep;               // [n_reads]
     int32_t* n_seeds;             // [n_reads] -> exclusive scan in seed_off

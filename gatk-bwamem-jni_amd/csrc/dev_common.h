@@ -68,6 +68,52 @@ DEV void extend_forward(const DevIndex& ix, const Intv& ik, Intv ok[4])
     for (int i = 0; i < 4; ++i) { uint64_t t = ok[i].x0; ok[i].x0 = ok[i].x1; ok[i].x1 = t; }
 }
 
+// occ(k,.) and occ(l,.) for k <= l.  When both ranks fall into the same 128-symbol block (the common case once an
+// interval is small) the 64-byte line is fetched once -- upstream's bwt_2occ4 makes the same distinction.
+DEV void occ4_pair(const DevIndex& ix, uint64_t k, uint64_t l, uint64_t tk[4], uint64_t tl[4])
+{
+    const uint64_t kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
+    if (k == (uint64_t)-1 || l == (uint64_t)-1 || (kk >> 7) != (ll >> 7)) { occ4(ix, k, tk); occ4(ix, l, tl); return; }
+    const uint4* p = (const uint4*)(ix.bwt + (kk >> 7 << 4));
+    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    const int nk = (int)(kk & 127) + 1, nl = (int)(ll & 127) + 1;
+    uint32_t a1 = 0, a2 = 0, a3 = 0, b1 = 0, b2 = 0, b3 = 0;
+    cnt_word(q2.x, nk, a1, a2, a3);       cnt_word(q2.x, nl, b1, b2, b3);
+    cnt_word(q2.y, nk - 16, a1, a2, a3);  cnt_word(q2.y, nl - 16, b1, b2, b3);
+    cnt_word(q2.z, nk - 32, a1, a2, a3);  cnt_word(q2.z, nl - 32, b1, b2, b3);
+    cnt_word(q2.w, nk - 48, a1, a2, a3);  cnt_word(q2.w, nl - 48, b1, b2, b3);
+    cnt_word(q3.x, nk - 64, a1, a2, a3);  cnt_word(q3.x, nl - 64, b1, b2, b3);
+    cnt_word(q3.y, nk - 80, a1, a2, a3);  cnt_word(q3.y, nl - 80, b1, b2, b3);
+    cnt_word(q3.z, nk - 96, a1, a2, a3);  cnt_word(q3.z, nl - 96, b1, b2, b3);
+    cnt_word(q3.w, nk - 112, a1, a2, a3); cnt_word(q3.w, nl - 112, b1, b2, b3);
+    const uint64_t c0 = (uint64_t)q0.y << 32 | q0.x, c1 = (uint64_t)q0.w << 32 | q0.z, c2 = (uint64_t)q1.y << 32 | q1.x, c3 = (uint64_t)q1.w << 32 | q1.z;
+    tk[0] = c0 + (uint32_t)(nk - (int)(a1 + a2 + a3)); tk[1] = c1 + a1; tk[2] = c2 + a2; tk[3] = c3 + a3;
+    tl[0] = c0 + (uint32_t)(nl - (int)(b1 + b2 + b3)); tl[1] = c1 + b1; tl[2] = c2 + b2; tl[3] = c3 + b3;
+}
+
+// one interval of a bidirectional extension, kept in registers (no runtime-indexed ok[4] array):
+// is_back = 1: the interval of bP for b = c; is_back = 0: upstream's ok[c] of bwt_extend(..., 0), i.e. the
+// interval of P followed by base 3 - c.
+DEV Intv extend_one(const DevIndex& ix, const Intv& ik, int c, int is_back)
+{
+    const uint64_t xa = is_back ? ik.x0 : ik.x1, xb = is_back ? ik.x1 : ik.x0;   // xa: the side that is rank-extended
+    uint64_t tk[4], tl[4];
+    occ4_pair(ix, xa - 1, xa - 1 + ik.size, tk, tl);
+    const uint64_t s0 = tl[0] - tk[0], s1 = tl[1] - tk[1], s2 = tl[2] - tk[2], s3 = tl[3] - tk[3];
+    const uint64_t tkc = c == 0 ? tk[0] : c == 1 ? tk[1] : c == 2 ? tk[2] : tk[3];
+    const uint64_t sc = c == 0 ? s0 : c == 1 ? s1 : c == 2 ? s2 : s3;
+    const uint64_t l2c = c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3];
+    uint64_t other = xb + (xa <= ix.primary && xa + ik.size - 1 >= ix.primary);
+    other += (c < 3 ? s3 : 0) + (c < 2 ? s2 : 0) + (c < 1 ? s1 : 0);
+    Intv r;
+    const uint64_t na = l2c + 1 + tkc;
+    r.x0 = is_back ? na : other;
+    r.x1 = is_back ? other : na;
+    r.size = sc;
+    r.info = ik.info;
+    return r;
+}
+
 DEV void set_intv(const DevIndex& ix, int c, Intv& ik)
 {
     ik.x0 = ix.L2[c] + 1;

@@ -9,26 +9,33 @@
 #include "dev_common.h"
 #include "kernels.h"
 
+// Per-read interval vectors live in global scratch laid out [entry][lane]: when the 64 reads of a wave push or
+// read entry e together, the wave touches one contiguous 2 KB span instead of 64 scattered lines.
 struct IntvVec {
-    Intv* a; int n; int cap;
-    __device__ bool push(const Intv& v) { if (n >= cap) return false; a[n++] = v; return true; }
+    Intv* a; int n; int cap; int stride;
+    __device__ Intv get(int i) const { return a[(size_t)i * stride]; }
+    __device__ void set(int i, const Intv& v) { a[(size_t)i * stride] = v; }
+    __device__ bool push(const Intv& v) { if (n >= cap) return false; a[(size_t)n * stride] = v; ++n; return true; }
 };
 
-DEV void vec_reverse(IntvVec& v)
+DEV void vec_reverse(IntvVec& v, int from = 0)
 {
-    for (int i = 0; i < v.n >> 1; ++i) { Intv t = v.a[i]; v.a[i] = v.a[v.n - 1 - i]; v.a[v.n - 1 - i] = t; }
+    for (int i = from, j = v.n - 1; i < j; ++i, --j) { Intv t = v.get(i); v.set(i, v.get(j)); v.set(j, t); }
 }
 
-// all SMEMs through position x with interval size >= min_intv; returns the next x.
+// all SMEMs through position x with interval size >= min_intv, appended to mem when at least min_seed_len long
+// (the caller's filter, fused so no intermediate vector is needed); returns the next x.
 // Forward-extend recording each size change, then backward-extend every candidate in lock-step,
 // longest first (App. B "SMEM(x, min_intv)").
-DEV int smem1(const DevIndex& ix, int len, const uint8_t* q, int x, int min_intv,
+DEV int smem1(const DevIndex& ix, int len, const uint8_t* q, int x, int min_intv, int min_seed_len,
               IntvVec& mem, IntvVec& v0, IntvVec& v1, uint32_t& n_ext, bool& ovf)
 {
-    Intv ik, ok[4];
+    Intv ik, ok;
     IntvVec *prev = &v0, *curr = &v1, *swap;
     int i, j, c;
-    mem.n = 0;
+    const int mem0 = mem.n;
+    uint64_t last_start = ~0ull;                 // start of the most recently emitted match (before the length filter)
+    bool any = false;
     if (q[x] > 3) return x + 1;
     if (min_intv < 1) min_intv = 1;
     set_intv(ix, q[x], ik);
@@ -36,12 +43,12 @@ DEV int smem1(const DevIndex& ix, int len, const uint8_t* q, int x, int min_intv
     for (i = x + 1, curr->n = 0; i < len; ++i) {
         if (q[i] < 4) {
             c = 3 - q[i];
-            extend_forward(ix, ik, ok); ++n_ext;
-            if (ok[c].size != ik.size) {
+            ok = extend_one(ix, ik, c, 0); ++n_ext;
+            if (ok.size != ik.size) {
                 if (!curr->push(ik)) { ovf = true; return len; }
-                if (ok[c].size < (uint64_t)min_intv) break;
+                if (ok.size < (uint64_t)min_intv) break;
             }
-            ik = ok[c]; ik.info = (uint64_t)(i + 1);
+            ik = ok; ik.info = (uint64_t)(i + 1);
         } else {
             if (!curr->push(ik)) { ovf = true; return len; }
             break;
@@ -49,49 +56,50 @@ DEV int smem1(const DevIndex& ix, int len, const uint8_t* q, int x, int min_intv
     }
     if (i == len) { if (!curr->push(ik)) { ovf = true; return len; } }
     vec_reverse(*curr);
-    int ret = (int)curr->a[0].info;
+    int ret = (int)curr->get(0).info;
     swap = curr; curr = prev; prev = swap;
     for (i = x - 1; i >= -1; --i) {
         c = i < 0 ? -1 : q[i] < 4 ? q[i] : -1;
         for (j = 0, curr->n = 0; j < prev->n; ++j) {
-            Intv p = prev->a[j];
-            if (c >= 0) { extend_backward(ix, p, ok); ++n_ext; }
-            if (c < 0 || ok[c].size < (uint64_t)min_intv) {
+            Intv p = prev->get(j);
+            if (c >= 0) { ok = extend_one(ix, p, c, 1); ++n_ext; }
+            if (c < 0 || ok.size < (uint64_t)min_intv) {
                 if (curr->n == 0) {
-                    if (mem.n == 0 || (uint64_t)(i + 1) < mem.a[mem.n - 1].info >> 32) {
+                    if (!any || (uint64_t)(i + 1) < last_start) {
+                        any = true; last_start = (uint64_t)(i + 1);
                         ik = p; ik.info |= (uint64_t)(i + 1) << 32;
-                        if (!mem.push(ik)) { ovf = true; return len; }
+                        if ((int)((uint32_t)ik.info - (uint32_t)(ik.info >> 32)) >= min_seed_len) { if (!mem.push(ik)) { ovf = true; return len; } }
                     }
                 }
-            } else if (curr->n == 0 || ok[c].size != curr->a[curr->n - 1].size) {
-                ok[c].info = p.info;
-                if (!curr->push(ok[c])) { ovf = true; return len; }
+            } else if (curr->n == 0 || ok.size != curr->get(curr->n - 1).size) {
+                ok.info = p.info;
+                if (!curr->push(ok)) { ovf = true; return len; }
             }
         }
         if (curr->n == 0) break;
         swap = curr; curr = prev; prev = swap;
     }
-    vec_reverse(mem);
+    vec_reverse(mem, mem0);                       // this call's matches in order of start
     return ret;
 }
 
 // pass 3: greedy forward seed (row a5)
 DEV int seed_strategy1(const DevIndex& ix, int len, const uint8_t* q, int x, int min_len, int max_intv, Intv& mem, uint32_t& n_ext)
 {
-    Intv ik, ok[4];
+    Intv ik, ok;
     mem.x0 = mem.x1 = mem.size = mem.info = 0;
     if (q[x] > 3) return x + 1;
     set_intv(ix, q[x], ik);
     for (int i = x + 1; i < len; ++i) {
         if (q[i] < 4) {
             int c = 3 - q[i];
-            extend_forward(ix, ik, ok); ++n_ext;
-            if (ok[c].size < (uint64_t)(int64_t)max_intv && i - x >= min_len) {
-                mem = ok[c];
+            ok = extend_one(ix, ik, c, 0); ++n_ext;
+            if (ok.size < (uint64_t)(int64_t)max_intv && i - x >= min_len) {
+                mem = ok;
                 mem.info = (uint64_t)x << 32 | (uint32_t)(i + 1);
                 return i + 1;
             }
-            ik = ok[c];
+            ik = ok;
         } else return i + 1;
     }
     return len;
@@ -112,8 +120,6 @@ __global__ void k_encode(uint8_t* seq, int64_t n_bytes)
     }
 }
 
-struct IntvInfoLt { __device__ bool operator()(const Intv& a, const Intv& b) const { return a.info < b.info; } };
-
 // mem_collect_intv (row a6) + the per-read bookkeeping mem_chain does before looking up the SA:
 // l_rep (repetitive fraction numerator) and the number of occurrences each interval contributes.
 __global__ void k_seed(DevIndex ix, MemOpt opt, TileView tv)
@@ -123,36 +129,26 @@ __global__ void k_seed(DevIndex ix, MemOpt opt, TileView tv)
     if (r < tv.n_reads) {
         const uint8_t* q = tv.seq + tv.seq_off[r];
         int len = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
-        IntvVec mem  = { tv.intv + (size_t)r * tv.intv_cap, 0, tv.intv_cap };
-        Intv* sc = tv.smem_scratch + (size_t)r * 3 * tv.smem_cap;
-        IntvVec mem1 = { sc, 0, tv.smem_cap };
-        IntvVec v0   = { sc + tv.smem_cap, 0, tv.smem_cap };
-        IntvVec v1   = { sc + 2 * (size_t)tv.smem_cap, 0, tv.smem_cap };
+        // scratch of wave-group g = r/64: [2 vectors][smem_cap entries][64 lanes]
+        Intv* sc = tv.smem_scratch + ((size_t)(r >> 6) * 2 * tv.smem_cap) * 64 + (r & 63);
+        IntvVec v0 = { sc, 0, tv.smem_cap, 64 };
+        IntvVec v1 = { sc + (size_t)tv.smem_cap * 64, 0, tv.smem_cap, 64 };
+        IntvVec mem = { tv.intv + (size_t)r * tv.intv_cap, 0, tv.intv_cap, 1 };
         bool ovf = false;
         int n_seeds = 0, l_rep = 0;
         if (len >= opt.min_seed_len) {
             int x = 0;
             int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
             while (x < len && !ovf) {                       // pass 1: all SMEMs
-                if (q[x] < 4) {
-                    x = smem1(ix, len, q, x, 1, mem1, v0, v1, n_ext, ovf);
-                    for (int i = 0; i < mem1.n && !ovf; ++i) {
-                        Intv p = mem1.a[i];
-                        int slen = (int)((uint32_t)p.info - (uint32_t)(p.info >> 32));
-                        if (slen >= opt.min_seed_len) { if (!mem.push(p)) ovf = true; }
-                    }
-                } else ++x;
+                if (q[x] < 4) x = smem1(ix, len, q, x, 1, opt.min_seed_len, mem, v0, v1, n_ext, ovf);
+                else ++x;
             }
             int old_n = mem.n;
             for (int k = 0; k < old_n && !ovf; ++k) {       // pass 2: re-seed long, rare SMEMs
-                Intv p = mem.a[k];
+                Intv p = mem.get(k);
                 int start = (int)(p.info >> 32), end = (int)(int32_t)p.info;
                 if (end - start < split_len || p.size > (uint64_t)(int64_t)opt.split_width) continue;
-                smem1(ix, len, q, (start + end) >> 1, (int)(p.size + 1), mem1, v0, v1, n_ext, ovf);
-                for (int i = 0; i < mem1.n && !ovf; ++i) {
-                    Intv m = mem1.a[i];
-                    if ((int)((uint32_t)m.info - (uint32_t)(m.info >> 32)) >= opt.min_seed_len) { if (!mem.push(m)) ovf = true; }
-                }
+                smem1(ix, len, q, (start + end) >> 1, (int)(p.size + 1), opt.min_seed_len, mem, v0, v1, n_ext, ovf);
             }
             if (opt.max_mem_intv > 0) {                     // pass 3: greedy forward seeds
                 x = 0;
@@ -165,7 +161,14 @@ __global__ void k_seed(DevIndex ix, MemOpt opt, TileView tv)
                 }
             }
             if (!ovf) {
-                ks_introsort((size_t)mem.n, mem.a, IntvInfoLt());
+                // sort by info.  Intervals with equal info are the same substring, hence identical records, so the
+                // order upstream's unstable sort leaves them in is unobservable: a plain insertion sort suffices.
+                for (int i = 1; i < mem.n; ++i) {
+                    Intv t = mem.a[i];
+                    int j = i;
+                    while (j > 0 && mem.a[j - 1].info > t.info) { mem.a[j] = mem.a[j - 1]; --j; }
+                    mem.a[j] = t;
+                }
                 int b = 0, e = 0;
                 int32_t* iso = tv.intv_seed_off + (size_t)r * tv.intv_cap;
                 for (int i = 0; i < mem.n; ++i) {

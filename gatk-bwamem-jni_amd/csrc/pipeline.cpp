@@ -69,7 +69,7 @@ struct Workspace {
     bool ensure_reads(int T_, int L_, int intv_cap_, int out_cap_, int64_t post_per_read_) {
         T = T_; L = L_; intv_cap = intv_cap_; smem_cap = L_ + 2; out_cap = out_cap_; post_per_read = post_per_read_;
         size_t t = (size_t)T;
-        return intv.ensure(t * intv_cap * sizeof(Intv)) && n_intv.ensure(t * 4) && smem.ensure(t * 3 * smem_cap * sizeof(Intv))
+        return intv.ensure(t * intv_cap * sizeof(Intv)) && n_intv.ensure(t * 4) && smem.ensure(((t + 63) / 64 * 64) * 2 * smem_cap * sizeof(Intv))
             && l_rep.ensure(t * 4) && n_seeds.ensure(t * 4) && seed_off.ensure((t + 1) * 8) && intv_seed_off.ensure(t * intv_cap * 4)
             && n_chains.ensure(t * 4) && n_regs.ensure(t * 4) && out.ensure(t * out_cap) && out_len.ensure(t * 4)
             && out_off.ensure((t + 1) * 8) && post.ensure(t * (size_t)post_per_read) && err.ensure(64) && cnt.ensure(sizeof(DevCounters));
@@ -329,7 +329,7 @@ static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes
             int len = (int)(b->h_off[r1 + 1] - b->h_off[r1] - 1);
             int L1 = std::max(L0, len);
             int icap = std::max(64, L1 + 8) * intv_cap_scale;
-            int64_t pr = (int64_t)icap * (sizeof(Intv) + 4) + 3 * (int64_t)(L1 + 2) * sizeof(Intv) + out_cap + post_bytes_per_read(L1, opt) + 64 * 300;
+            int64_t pr = (int64_t)icap * (sizeof(Intv) + 4) + 2 * (int64_t)(L1 + 2) * sizeof(Intv) + out_cap + post_bytes_per_read(L1, opt) + 64 * 300;
             if (r1 > r0 + 1 && pr * (int64_t)(r1 - r0 + 1) > budget && ((r1 - r0) & 1) == 0) break;
             L0 = L1; ++r1;
         }
@@ -481,7 +481,7 @@ static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, b
             int len = (int)(b->h_off[r1 + 1] - b->h_off[r1] - 1);
             int L1 = std::max(L0, len);
             int icap = std::max(64, L1 + 8) * intv_cap_scale;
-            int64_t pr = (int64_t)icap * (sizeof(Intv) + 4) + 3 * (int64_t)(L1 + 2) * sizeof(Intv) + out_cap + post_bytes_per_read(L1, opt) + 64 * 300;
+            int64_t pr = (int64_t)icap * (sizeof(Intv) + 4) + 2 * (int64_t)(L1 + 2) * sizeof(Intv) + out_cap + post_bytes_per_read(L1, opt) + 64 * 300;
             if (r1 > r0 && pr * (int64_t)(r1 - r0 + 1) > budget) break;
             L0 = L1; per_read = pr; ++r1;
         }
