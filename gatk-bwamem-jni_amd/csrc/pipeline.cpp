@@ -17,6 +17,8 @@
 #include <sys/stat.h>
 #include <sys/mman.h>
 #include <mutex>
+#include <thread>
+#include <atomic>
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -111,6 +113,7 @@ struct bwaidx_s {
     DevBuf d_bwt, d_sa, d_pac, d_ann_off, d_ann_len, d_ann_alt, d_name_off, d_names, d_log;
     std::mutex mu;                  // one call at a time per index/device
     Workspace ws;
+    std::vector<Workspace*> extra_ws;   // further tiles in flight (one stream + host thread each)
 };
 
 struct TileOut { uint8_t* d = nullptr; size_t bytes = 0; };
@@ -175,6 +178,8 @@ static void free_index(bwaidx_s* ix)
     DevBuf* all[] = { &ix->d_bwt, &ix->d_sa, &ix->d_pac, &ix->d_ann_off, &ix->d_ann_len, &ix->d_ann_alt, &ix->d_name_off, &ix->d_names, &ix->d_log };
     for (DevBuf* b : all) b->release();
     ix->ws.release();
+    for (Workspace* w : ix->extra_ws) { w->release(); delete w; }
+    ix->extra_ws.clear();
 }
 
 // ------------------------------------------------------------------------------------------ timing
@@ -455,6 +460,107 @@ static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes
 #undef PE_REQ
 }
 
+struct TileSpec { uint32_t r0, r1; int L; };
+
+// cut the batch into tiles from a per-workspace device-memory budget (pairs are never split when even = true)
+static std::vector<TileSpec> plan_tiles(const bwamem_batch_s* b, const MemOpt& opt, bool even)
+{
+    const char* env_t = getenv("BWAMEM_HIP_TILE");
+    const char* env_gb = getenv("BWAMEM_HIP_TILE_GB");
+    const int64_t budget = (int64_t)(env_gb ? atoi(env_gb) : 20) << 30;
+    uint32_t max_T = env_t ? (uint32_t)atoi(env_t) : 262144u;
+    if (even) max_T = std::max(2u, max_T & ~1u);
+    std::vector<TileSpec> tiles;
+    uint32_t r0 = 0;
+    while (r0 < b->n_reads) {
+        int L0 = 1;
+        uint32_t r1 = r0;
+        while (r1 < b->n_reads && r1 - r0 < max_T) {
+            int len = (int)(b->h_off[r1 + 1] - b->h_off[r1] - 1);
+            int L1 = std::max(L0, len);
+            int64_t pr = (int64_t)std::max(64, L1 + 8) * (sizeof(Intv) + 4) + 2 * (int64_t)(L1 + 2) * sizeof(Intv) + 512 + post_bytes_per_read(L1, opt) + 64 * 300;
+            if (r1 > r0 + (even ? 1u : 0u) && pr * (int64_t)(r1 - r0 + 1) > budget && (!even || ((r1 - r0) & 1) == 0)) break;
+            L0 = L1; ++r1;
+        }
+        TileSpec t; t.r0 = r0; t.r1 = r1; t.L = L0;
+        tiles.push_back(t);
+        r0 = r1;
+    }
+    return tiles;
+}
+
+// one single-end tile, start to packed response, on the workspace's own stream
+static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_batch_s* b, int64_t read_id0, const TileSpec& spec,
+                        TileOut& to, int& intv_cap_scale, int& out_cap)
+{
+    const uint32_t r0 = spec.r0;
+    const int T = (int)(spec.r1 - spec.r0), L = spec.L;
+    int intv_cap = std::max(64, L + 8) * intv_cap_scale;
+    int attempts = 0;
+    for (;;) {
+        if (++attempts > 8) { fprintf(stderr, "[bwamem_hip] tile could not be sized after 8 attempts\n"); return false; }
+        if (!ws.ensure_reads(T, L, intv_cap, out_cap, post_bytes_per_read(L, opt))) return false;
+        if (!ws.ensure_seeds(std::max<int64_t>(ws.seed_cap, (int64_t)T * 16))) return false;
+        TileView tv = ws.view();
+        tv.n_reads = T; tv.max_len = L; tv.read_id0 = read_id0 + r0;
+        tv.seq = b->d_seq.as<uint8_t>(); tv.seq_off = b->d_off.as<int64_t>() + r0;
+        HIP_OK(hipMemsetAsync(ws.err.p, 0, 64, ws.stream));
+        HIP_OK(hipMemsetAsync(ws.cnt.p, 0, sizeof(DevCounters), ws.stream));
+        TIMED(ws, K_SEED, launch_seed(ws.stream, ix->d, opt, tv));
+        TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_seeds, tv.seed_off, T));
+        int64_t n_occ = 0; int32_t err = 0; int32_t errv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIP_OK(hipMemcpyAsync(&n_occ, tv.seed_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
+        HIP_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
+        HIP_OK(hipStreamSynchronize(ws.stream));
+        if (err & ERR_INTV_CAP) { intv_cap *= 2; intv_cap_scale *= 2; { std::lock_guard<std::mutex> lk(g_stats.mu); ++g_stats.s.n_retries; } continue; }
+        if (n_occ > ws.seed_cap) {
+            if (!ws.ensure_seeds(n_occ + n_occ / 4)) return false;
+            TileView t2 = ws.view();
+            t2.n_reads = T; t2.max_len = L; t2.read_id0 = tv.read_id0; t2.seq = tv.seq; t2.seq_off = tv.seq_off;
+            tv = t2;
+        }
+        TIMED(ws, K_SA, launch_sa(ws.stream, ix->d, opt, tv, n_occ));
+        TIMED(ws, K_CHAIN, launch_chain(ws.stream, ix->d, opt, tv, ws.chain_store.as<Chain>()));
+        TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
+        if (getenv("BWAMEM_HIP_DUMP") && T <= 64) debug_dump(ws, tv, T);
+        TIMED(ws, K_POST, launch_post1(ws.stream, ix->d, opt, tv));
+        TIMED(ws, K_FINAL, launch_final_se(ws.stream, ix->d, opt, tv));
+        TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.out_len, tv.out_off, T));
+        int64_t out_total = 0;
+        DevCounters hc;
+        HIP_OK(hipMemcpyAsync(&out_total, tv.out_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
+        HIP_OK(hipMemcpyAsync(&hc, tv.cnt, sizeof hc, hipMemcpyDeviceToHost, ws.stream));
+        HIP_OK(hipMemcpyAsync(errv, tv.err, sizeof errv, hipMemcpyDeviceToHost, ws.stream));
+        HIP_OK(hipStreamSynchronize(ws.stream));
+        err = errv[0];
+        if (err) {
+            { std::lock_guard<std::mutex> lk(g_stats.mu); ++g_stats.s.n_retries; }
+            if (err & ERR_BAD_REG) { fprintf(stderr, "[bwamem_hip] internal error: extension produced an invalid region (tile read %d of call read %lld: n=%d qb=%d qe=%d rb=%d re=%d score=%d)\n", errv[1], (long long)(read_id0 + r0 + errv[1]), errv[2], errv[3], errv[4], errv[5], errv[6], errv[7]); return false; }
+            if (err & ERR_LONG_READ) { fprintf(stderr, "[bwamem_hip] reads long enough to need seed re-scoring (mem_flt_chained_seeds) are not supported on the device path yet\n"); return false; }
+            if (err & ERR_BTREE) { fprintf(stderr, "[bwamem_hip] internal error: chain B-tree pool exhausted\n"); return false; }
+            if (err & (ERR_SCRATCH | ERR_CIGAR_CAP)) { fprintf(stderr, "[bwamem_hip] internal error: post-processing scratch exhausted (err=%d)\n", err); return false; }
+            if (err & ERR_OUT_CAP) { out_cap *= 4; continue; }
+            fprintf(stderr, "[bwamem_hip] device error flags %d\n", err); return false;
+        }
+        to.bytes = (size_t)out_total; to.d = nullptr;
+        if (out_total > 0) {
+            HIP_OK(hipMalloc((void**)&to.d, (size_t)out_total));
+            TIMED(ws, K_PACK, launch_pack(ws.stream, tv, to.d));
+            HIP_OK(hipStreamSynchronize(ws.stream));
+        }
+        {
+            std::lock_guard<std::mutex> lk(g_stats.mu);
+            g_stats.s.n_reads += T; g_stats.s.n_ext += hc.n_ext; g_stats.s.n_lf += hc.n_lf; g_stats.s.n_sa += hc.n_sa;
+            g_stats.s.n_dp_cells += hc.n_dp_cells; ++g_stats.s.n_tiles;
+        }
+        timed_collect(ws);
+        return true;
+    }
+}
+
+// Tiles are independent, and every kernel of a tile ends in a tail of a few long-running reads; several tiles are
+// therefore kept in flight on separate HIP streams (one host thread + workspace each) so that one tile's tail
+// overlaps the next tile's bulk.
 static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, bwamem_batch_s* b, int64_t read_id0)
 {
     HIP_OK(hipSetDevice(ix->device));
@@ -466,98 +572,32 @@ static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, b
     HIP_OK(hipMemcpyAsync(b->d_seq.p, b->d_raw.p, b->n_bytes, hipMemcpyDeviceToDevice, ws.stream));
     TIMED(ws, K_ENCODE, launch_encode(ws.stream, b->d_seq.as<uint8_t>(), (int64_t)b->n_bytes));
     if (opt.flag & MEM_F_PE) return align_batch_pe(ix, opt, pes, b, read_id0);
-    const char* env_t = getenv("BWAMEM_HIP_TILE");
-    int intv_cap_scale = 1, out_cap = 512;
-    int64_t seed_cap_hint = 0;
-    uint32_t r0 = 0;
-    while (r0 < b->n_reads) {
-        // tile size from a device-memory budget
-        int64_t budget = (int64_t)24 << 30;
-        int L0 = 1;
-        uint32_t r1 = r0;
-        int64_t per_read = 0;
-        uint32_t max_T = env_t ? (uint32_t)atoi(env_t) : 262144u;
-        while (r1 < b->n_reads && r1 - r0 < max_T) {
-            int len = (int)(b->h_off[r1 + 1] - b->h_off[r1] - 1);
-            int L1 = std::max(L0, len);
-            int icap = std::max(64, L1 + 8) * intv_cap_scale;
-            int64_t pr = (int64_t)icap * (sizeof(Intv) + 4) + 2 * (int64_t)(L1 + 2) * sizeof(Intv) + out_cap + post_bytes_per_read(L1, opt) + 64 * 300;
-            if (r1 > r0 && pr * (int64_t)(r1 - r0 + 1) > budget) break;
-            L0 = L1; per_read = pr; ++r1;
+    HIP_OK(hipStreamSynchronize(ws.stream));
+    timed_collect(ws);
+    const std::vector<TileSpec> specs = plan_tiles(b, opt, false);
+    b->tiles.assign(specs.size(), TileOut());
+    const char* env_s = getenv("BWAMEM_HIP_STREAMS");
+    int n_workers = std::max(1, std::min<int>((int)specs.size(), env_s ? atoi(env_s) : 3));
+    while ((int)ix->extra_ws.size() < n_workers - 1) ix->extra_ws.push_back(new Workspace());
+    std::atomic<size_t> next(0);
+    std::atomic<bool> failed(false);
+    auto worker = [&](int k) {
+        Workspace& w = k == 0 ? ix->ws : *ix->extra_ws[k - 1];
+        if (hipSetDevice(ix->device) != hipSuccess) { failed = true; return; }
+        if (!w.stream && hipStreamCreate(&w.stream) != hipSuccess) { failed = true; return; }
+        int intv_cap_scale = 1, out_cap = 512;
+        while (!failed) {
+            size_t i = next++;
+            if (i >= specs.size()) break;
+            if (!run_tile_se(ix, w, opt, b, read_id0, specs[i], b->tiles[i], intv_cap_scale, out_cap)) failed = true;
         }
-        (void)per_read;
-        const int T = (int)(r1 - r0), L = L0;
-        int intv_cap = std::max(64, L + 8) * intv_cap_scale;
-        bool tile_done = false;
-        int attempts = 0;
-        while (!tile_done) {
-            if (++attempts > 8) { fprintf(stderr, "[bwamem_hip] tile could not be sized after 8 attempts\n"); return false; }
-            if (!ws.ensure_reads(T, L, intv_cap, out_cap, post_bytes_per_read(L, opt))) return false;
-            if (!ws.ensure_seeds(std::max<int64_t>(seed_cap_hint, (int64_t)T * 16))) return false;
-            TileView tv = ws.view();
-            tv.n_reads = T; tv.max_len = L; tv.read_id0 = read_id0 + r0;
-            tv.seq = b->d_seq.as<uint8_t>(); tv.seq_off = b->d_off.as<int64_t>() + r0;
-            HIP_OK(hipMemsetAsync(ws.err.p, 0, 64, ws.stream));
-            HIP_OK(hipMemsetAsync(ws.cnt.p, 0, sizeof(DevCounters), ws.stream));
-            TIMED(ws, K_SEED, launch_seed(ws.stream, ix->d, opt, tv));
-            TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_seeds, tv.seed_off, T));
-            int64_t n_occ = 0; int32_t err = 0; int32_t errv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            HIP_OK(hipMemcpyAsync(&n_occ, tv.seed_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
-            HIP_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
-            HIP_OK(hipStreamSynchronize(ws.stream));
-            HIP_OK(hipGetLastError());
-            if (err & ERR_INTV_CAP) { intv_cap *= 2; intv_cap_scale *= 2; { std::lock_guard<std::mutex> lk(g_stats.mu); ++g_stats.s.n_retries; } continue; }
-            if (n_occ > ws.seed_cap) {
-                seed_cap_hint = n_occ + n_occ / 4;
-                if (!ws.ensure_seeds(seed_cap_hint)) return false;
-                tv = ws.view();
-                tv.n_reads = T; tv.max_len = L; tv.read_id0 = read_id0 + r0;
-                tv.seq = b->d_seq.as<uint8_t>(); tv.seq_off = b->d_off.as<int64_t>() + r0;
-            }
-            TIMED(ws, K_SA, launch_sa(ws.stream, ix->d, opt, tv, n_occ));
-            TIMED(ws, K_CHAIN, launch_chain(ws.stream, ix->d, opt, tv, ws.chain_store.as<Chain>()));
-            TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
-            if (getenv("BWAMEM_HIP_DUMP") && T <= 64) debug_dump(ws, tv, T);
-            TIMED(ws, K_POST, launch_post1(ws.stream, ix->d, opt, tv));
-            TIMED(ws, K_FINAL, launch_final_se(ws.stream, ix->d, opt, tv));
-            TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.out_len, tv.out_off, T));
-            int64_t out_total = 0;
-            DevCounters hc;
-            HIP_OK(hipMemcpyAsync(&out_total, tv.out_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
-            HIP_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
-            HIP_OK(hipMemcpyAsync(&hc, tv.cnt, sizeof hc, hipMemcpyDeviceToHost, ws.stream));
-            HIP_OK(hipMemcpyAsync(errv, tv.err, sizeof errv, hipMemcpyDeviceToHost, ws.stream));
-            HIP_OK(hipStreamSynchronize(ws.stream));
-            HIP_OK(hipGetLastError());
-            if (err) {
-                { std::lock_guard<std::mutex> lk(g_stats.mu); ++g_stats.s.n_retries; }
-                if (err & ERR_BAD_REG) { fprintf(stderr, "[bwamem_hip] internal error: extension produced an invalid region (tile read %d of call read %lld: n=%d qb=%d qe=%d rb=%d re=%d score=%d)\n", errv[1], (long long)(read_id0 + r0 + errv[1]), errv[2], errv[3], errv[4], errv[5], errv[6], errv[7]); return false; }
-                if (err & ERR_LONG_READ) { fprintf(stderr, "[bwamem_hip] reads long enough to need seed re-scoring (mem_flt_chained_seeds) are not supported on the device path yet\n"); return false; }
-                if (err & ERR_BTREE) { fprintf(stderr, "[bwamem_hip] internal error: chain B-tree pool exhausted\n"); return false; }
-                if (err & (ERR_SCRATCH | ERR_CIGAR_CAP)) { fprintf(stderr, "[bwamem_hip] internal error: post-processing scratch exhausted (err=%d)\n", err); return false; }
-                if (err & ERR_OUT_CAP) { out_cap *= 4; continue; }
-                fprintf(stderr, "[bwamem_hip] device error flags %d\n", err); return false;
-            }
-            TileOut to;
-            to.bytes = (size_t)out_total;
-            if (out_total > 0) {
-                HIP_OK(hipMalloc((void**)&to.d, (size_t)out_total));
-                TIMED(ws, K_PACK, launch_pack(ws.stream, tv, to.d));
-                HIP_OK(hipStreamSynchronize(ws.stream));
-                HIP_OK(hipGetLastError());
-            }
-            b->tiles.push_back(to);
-            b->result_bytes += to.bytes;
-            {
-                std::lock_guard<std::mutex> lk(g_stats.mu);
-                g_stats.s.n_reads += T; g_stats.s.n_ext += hc.n_ext; g_stats.s.n_lf += hc.n_lf; g_stats.s.n_sa += hc.n_sa;
-                g_stats.s.n_dp_cells += hc.n_dp_cells; ++g_stats.s.n_tiles;
-            }
-            timed_collect(ws);
-            tile_done = true;
-        }
-        r0 = r1;
-    }
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_workers; ++k) th.emplace_back(worker, k);
+    worker(0);
+    for (std::thread& t : th) t.join();
+    if (failed) return false;
+    for (const TileOut& t : b->tiles) b->result_bytes += t.bytes;
     return true;
 }
 

@@ -4,6 +4,7 @@
 #include <sys/mman.h>
 #include <stdio.h>
 #include <vector>
+#include <mutex>
 
 dim3 threadIdx, blockIdx, blockDim, gridDim;
 
@@ -57,8 +58,11 @@ static void trampoline()
     swapcontext(&f->ctx, &g_sched);
 }
 
+static std::mutex g_launch_mu;     // the fiber scheduler state is process-global: launches from several host threads are serialised
+
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body)
 {
+    std::lock_guard<std::mutex> lk(g_launch_mu);
     const unsigned nt = block.x;
     gridDim = grid; blockDim = block;
     g_body = &body;

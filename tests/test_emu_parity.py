@@ -55,3 +55,12 @@ def test_emu_paired_end(emu, oracle, rota_img, small_genome):
             req = B.pack_request(reads)
             assert emu.align_raw(h, opts, req, pes) == oracle.align_raw(ho, opts, req, pes)
         emu.destroy_index(h); oracle.destroy_index(ho)
+
+
+def test_emu_concurrent_tiles(emu, oracle, small_genome, monkeypatch):
+    """several tiles in flight (one host thread + stream each) must give the single-tile bytes"""
+    seqs, img = small_genome
+    reads = B.simulate_reads(seqs, 30, length=100, seed=9, sub=0.02, indel=0.003)
+    monkeypatch.setenv("BWAMEM_HIP_TILE", "7")
+    monkeypatch.setenv("BWAMEM_HIP_STREAMS", "3")
+    _cmp(emu, oracle, img, reads)
