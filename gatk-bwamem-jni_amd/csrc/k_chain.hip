@@ -6,8 +6,10 @@
 // because its insertion rule decides the order of chains with equal keys, and that order
 // feeds the unstable weight sort downstream.  Chains hold their seeds as a
 // linked list threaded through the occurrence array, so no per-chain allocation exists.
+#include <math.h>
 #include "dev_common.h"
 #include "kernels.h"
+#include "sw_common.h"
 
 #define BT_T 5
 #define BT_MAXK (2 * BT_T - 1)
@@ -277,13 +279,6 @@ __global__ void k_chain(DevIndex ix, MemOpt opt, TileView tv, Chain* chain_store
         n_chn = k;
     }
 
-    // ---- mem_flt_chained_seeds (row a10) is active only for long reads (5.5 ln L <= 0.05 L)
-    {
-        double min_l = opt.min_chain_weight ? 1.1f * opt.min_chain_weight
-                     : 5.5f * (len < ix.log_tab_n ? ix.log_tab[len] : 1e30);
-        if (!(min_l > 0.05f * len) && n_chn > 0) atomicOr(tv.err, ERR_LONG_READ);
-    }
-
     // ---- lay the kept chains' seeds out contiguously, chain by chain
     {
         Seed* out = tv.cseeds;
@@ -300,6 +295,75 @@ __global__ void k_chain(DevIndex ix, MemOpt opt, TileView tv, Chain* chain_store
         }
     }
     tv.n_chains[r] = n_chn;
+}
+
+// mem_flt_chained_seeds + mem_seed_sw (row a10): for reads long enough that 5.5 ln L <= 0.05 L, every short seed is
+// re-scored by a local SW in a +-50 bp window and dropped when it scores below the HSP threshold.  One lane per read;
+// launched only for tiles that contain such reads.
+#define MEM_SHORT_EXT 50
+#define MEM_SHORT_LEN 200
+
+DEV int seed_sw(const DevIndex& ix, const MemOpt& opt, int l_query, const uint8_t* query, const Seed& s, SwScratch& W, int& err)
+{
+    const int64_t l_pac = ix.l_pac;
+    if (s.len >= MEM_SHORT_LEN) return -1;
+    int qb = s.qbeg, qe = s.qbeg + s.len, rid;
+    int64_t rb = s.rbeg, re = s.rbeg + s.len, mid = (rb + re) >> 1;
+    qb -= MEM_SHORT_EXT; qb = qb > 0 ? qb : 0;
+    qe += MEM_SHORT_EXT; qe = qe < l_query ? qe : l_query;
+    rb -= MEM_SHORT_EXT; rb = rb > 0 ? rb : 0;
+    re += MEM_SHORT_EXT; re = re < l_pac << 1 ? re : l_pac << 1;
+    if (rb < l_pac && l_pac < re) { if (mid < l_pac) re = l_pac; else rb = l_pac; }
+    if (qe - qb >= MEM_SHORT_LEN || re - rb >= MEM_SHORT_LEN) return -1;
+    bns_clamp(ix, rb, mid, re, rid);
+    SwIn I; I.ms = query + qb; I.l_ms = qe - qb; I.is_rev = 0; I.qrev = 0; I.t0 = rb; I.trev = 0;
+    // ksw_align2(..., KSW_XSTART): only the score of the first pass is used by the caller
+    KswR x = sw_core(ix, opt, I, 2, qe - qb, (int)(re - rb), KSW_XSTART, W, err);
+    return x.score;
+}
+
+__global__ void k_rescore(DevIndex ix, MemOpt opt, TileView tv)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= tv.n_reads) return;
+    const int l_query = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
+    const int n_chn = tv.n_chains[r];
+    if (n_chn == 0) return;
+    if (l_query >= ix.log_tab_n) { atomicOr(tv.err, ERR_SCRATCH); return; }
+    const double min_l = opt.min_chain_weight ? 1.1f * opt.min_chain_weight : 5.5f * ix.log_tab[l_query];
+    const int min_HSP_score = (int)(opt.a * min_l + .499);
+    if (min_l > 0.05f * l_query) return;             // short reads: nothing to do
+    const uint8_t* query = tv.seq + tv.seq_off[r];
+    int32_t hbuf[4 * (MEM_SHORT_LEN + 16)];
+    SwScratch W; W.cap_h = MEM_SHORT_LEN + 16; W.cap_b = 0; W.b = 0;
+    W.H0 = hbuf; W.H1 = hbuf + W.cap_h; W.E = hbuf + 2 * W.cap_h; W.Hmax = hbuf + 3 * W.cap_h;
+    Chain* chains = tv.chains + tv.seed_off[r];
+    int err = 0;
+    for (int i = 0; i < n_chn; ++i) {
+        Chain& c = chains[i];
+        Seed* seeds = tv.cseeds + tv.seed_off[r] + c.seed0;
+        int k = 0;
+        for (int j = 0; j < c.n; ++j) {
+            Seed s = seeds[j];
+            s.score = seed_sw(ix, opt, l_query, query, s, W, err);
+            if (s.score < 0 || s.score >= min_HSP_score) {
+                s.score = s.score < 0 ? s.len * opt.a : s.score;
+                seeds[k++] = s;
+            }
+        }
+        c.n = k;
+    }
+    if (err) atomicOr(tv.err, err);
+}
+
+void launch_rescore(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv)
+{
+    if (tv.n_reads <= 0) return;
+    // the shortest read that can trigger re-scoring has 5.5 ln L <= 0.05 L; skip the launch when no read of the tile can
+    double L = tv.max_len > 1 ? (double)tv.max_len : 2.0;
+    double min_l = opt.min_chain_weight ? 1.1f * opt.min_chain_weight : 5.5f * log(L);
+    if (min_l > 0.05f * L) return;
+    hipLaunchKernelGGL(k_rescore, dim3((tv.n_reads + 63) / 64), dim3(64), 0, st, ix, opt, tv);
 }
 
 void launch_chain(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, Chain* chain_store)

@@ -10,6 +10,7 @@
 #include "dev_common.h"
 #include "kernels.h"
 #include "post_common.h"
+#include "sw_common.h"
 
 
 // ------------------------------------------------------------------ insert-size candidates
@@ -50,136 +51,6 @@ __global__ void k_pestat_cand(DevIndex ix, MemOpt opt, TileView tv, int8_t* cand
         if (is && is <= opt.max_ins) dir = d;
     }
     cand_dir[pi] = (int8_t)dir; cand_is[pi] = is;
-}
-
-// ------------------------------------------------------------------ striped local SW (ksw_align2)
-#define KSW_XBYTE  0x10000
-#define KSW_XSTOP  0x20000
-#define KSW_XSUBO  0x40000
-#define KSW_XSTART 0x80000
-
-struct KswR { int score, te, qe, score2, te2, tb, qb; };
-
-struct SwIn {
-    const uint8_t* ms; int l_ms; int is_rev;     // query = ms or its reverse complement
-    int qrev;                                     // > 0: the first qrev query bases are read reversed (second pass)
-    int64_t t0; int trev;                         // target = reference from t0; the first trev bases reversed (second pass)
-};
-DEV int sw_q0(const SwIn& I, int i) { int c = I.is_rev ? I.ms[I.l_ms - 1 - i] : I.ms[i]; return I.is_rev ? (c < 4 ? 3 - c : 4) : c; }
-DEV int sw_q(const SwIn& I, int i) { return sw_q0(I, i < I.qrev ? I.qrev - 1 - i : i); }
-DEV int sw_t(const DevIndex& ix, const SwIn& I, int i) { return ref_base2(ix, I.t0 + (i < I.trev ? I.trev - 1 - i : i)); }
-
-struct SwScratch { int32_t* H0; int32_t* H1; int32_t* E; int32_t* Hmax; uint64_t* b; int cap_h, cap_b; };
-
-DEV int sat_u8(int x) { return x < 0 ? 0 : x > 255 ? 255 : x; }
-DEV int sat_i16(int x) { return x < -32768 ? -32768 : x > 32767 ? 32767 : x; }
-DEV int subs_u16(int a, int b) { int x = (int)(uint16_t)a - (int)(uint16_t)b; return x < 0 ? 0 : (int)(int16_t)(uint16_t)x; }
-
-DEV KswR sw_core(const DevIndex& ix, const MemOpt& opt, const SwIn& I, int size, int qlen, int tlen, int xtra, SwScratch& W, int& err)
-{
-    const int p = 8 * (3 - size), slen = (qlen + p - 1) / p, u8 = size == 1;
-    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
-    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    KswR r; r.score = 0; r.te = r.qe = r.score2 = r.te2 = r.tb = r.qb = -1;
-    if (slen * p > W.cap_h) { err |= ERR_SCRATCH; return r; }
-    int lo = 127, hi = 0;
-    for (int a = 0; a < 25; ++a) { if (opt.mat[a] < lo) lo = opt.mat[a]; if (opt.mat[a] > hi) hi = opt.mat[a]; }
-    const int shift = (256 - (lo & 0xff)) & 0xff, qmax = hi;
-    int n_b = 0, te = -1, gmax = 0;
-    const int minsc = (xtra & KSW_XSUBO) ? xtra & 0xffff : 0x10000;
-    const int endsc = (xtra & KSW_XSTOP) ? xtra & 0xffff : 0x10000;
-    int32_t *H0 = W.H0, *H1 = W.H1, *E = W.E, *Hmax = W.Hmax;
-    for (int i = 0; i < slen * p; ++i) { E[i] = 0; H0[i] = 0; Hmax[i] = 0; }
-    int h[16], f[16], mx[16];
-    for (int i = 0; i < tlen; ++i) {
-        const int tb = sw_t(ix, I, i);
-        int imax, done = 0;
-        for (int l = 0; l < p; ++l) { f[l] = 0; mx[l] = 0; }
-        h[0] = 0;
-        for (int l = 1; l < p; ++l) h[l] = H0[(slen - 1) * p + l - 1];
-        for (int j = 0; j < slen; ++j) {
-            for (int l = 0; l < p; ++l) {
-                int pos = j + l * slen;
-                int sc = (pos >= qlen ? 0 : opt.mat[tb * 5 + sw_q(I, pos)]) + (u8 ? shift : 0);
-                int hh, ee = E[j * p + l], t;
-                if (u8) { hh = sat_u8(h[l] + sc); hh = sat_u8(hh - shift); }
-                else hh = sat_i16(h[l] + sc);
-                hh = hh > ee ? hh : ee;
-                hh = hh > f[l] ? hh : f[l];
-                mx[l] = mx[l] > hh ? mx[l] : hh;
-                H1[j * p + l] = hh;
-                if (u8) { ee = sat_u8(ee - e_del); t = sat_u8(hh - oe_del); }
-                else    { ee = subs_u16(ee, e_del); t = subs_u16(hh, oe_del); }
-                ee = ee > t ? ee : t;
-                E[j * p + l] = ee;
-                if (u8) { f[l] = sat_u8(f[l] - e_ins); t = sat_u8(hh - oe_ins); }
-                else    { f[l] = subs_u16(f[l], e_ins); t = subs_u16(hh, oe_ins); }
-                f[l] = f[l] > t ? f[l] : t;
-                h[l] = H0[j * p + l];
-            }
-        }
-        for (int k = 0; k < 16 && !done; ++k) {          // lazy-F across segment boundaries
-            for (int l = p - 1; l > 0; --l) f[l] = f[l - 1];
-            f[0] = 0;
-            for (int j = 0; j < slen; ++j) {
-                int all = 1;
-                for (int l = 0; l < p; ++l) {
-                    int hh = H1[j * p + l];
-                    hh = hh > f[l] ? hh : f[l];
-                    H1[j * p + l] = hh;
-                    if (u8) { hh = sat_u8(hh - oe_ins); f[l] = sat_u8(f[l] - e_ins); if (sat_u8(f[l] - hh) != 0) all = 0; }
-                    else    { hh = subs_u16(hh, oe_ins); f[l] = subs_u16(f[l], e_ins); if (f[l] > hh) all = 0; }
-                }
-                if (all) { done = 1; break; }
-            }
-        }
-        imax = mx[0];
-        for (int l = 1; l < p; ++l) imax = imax > mx[l] ? imax : mx[l];
-        if (imax >= minsc) {
-            if (n_b == 0 || (int32_t)W.b[n_b - 1] + 1 != i) {
-                if (n_b >= W.cap_b) { err |= ERR_SCRATCH; return r; }
-                W.b[n_b++] = (uint64_t)imax << 32 | (uint32_t)i;
-            } else if ((int)(W.b[n_b - 1] >> 32) < imax) W.b[n_b - 1] = (uint64_t)imax << 32 | (uint32_t)i;
-        }
-        if (imax > gmax) {
-            gmax = imax; te = i;
-            for (int j = 0; j < slen * p; ++j) Hmax[j] = H1[j];
-            if (u8) { if (gmax + shift >= 255 || gmax >= endsc) break; }
-            else if (gmax >= endsc) break;
-        }
-        int32_t* S = H1; H1 = H0; H0 = S;
-    }
-    r.score = u8 ? (gmax + shift < 255 ? gmax : 255) : gmax;
-    r.te = te;
-    if (!u8 || r.score != 255) {
-        int max = -1, tmp, n = slen * p;
-        for (int i = 0; i < n; ++i) {
-            int v = Hmax[i];
-            if (v > max) { max = v; r.qe = i / p + i % p * slen; }
-            else if (v == max && (tmp = i / p + i % p * slen) < r.qe) r.qe = tmp;
-        }
-        if (n_b > 0) {
-            int i = (r.score + qmax - 1) / qmax;
-            int low = te - i, high = te + i;
-            for (i = 0; i < n_b; ++i) {
-                int e = (int32_t)W.b[i];
-                if ((e < low || e > high) && (int)(W.b[i] >> 32) > r.score2) { r.score2 = (int)(W.b[i] >> 32); r.te2 = e; }
-            }
-        }
-    }
-    return r;
-}
-
-DEV KswR sw_align2(const DevIndex& ix, const MemOpt& opt, SwIn I, int qlen, int tlen, int xtra, SwScratch& W, int& err)
-{
-    const int size = (xtra & KSW_XBYTE) ? 1 : 2;
-    I.qrev = 0; I.trev = 0;
-    KswR r = sw_core(ix, opt, I, size, qlen, tlen, xtra, W, err);
-    if ((xtra & KSW_XSTART) == 0 || ((xtra & KSW_XSUBO) && r.score < (xtra & 0xffff))) return r;
-    I.qrev = r.qe + 1; I.trev = r.te + 1;             // upstream reverses both prefixes in place, then runs over the full target
-    KswR rr = sw_core(ix, opt, I, size, r.qe + 1, tlen, KSW_XSTOP | r.score, W, err);
-    if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
-    return r;
 }
 
 // ------------------------------------------------------------------ mate rescue (mem_matesw)

@@ -8,6 +8,7 @@ void launch_seed(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const Ti
 void launch_scan(hipStream_t st, const int32_t* in, int64_t* out, int n);
 void launch_sa(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, int64_t n_occ);
 void launch_chain(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, Chain* chain_store);
+void launch_rescore(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 void launch_extend(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 void launch_post1(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 void launch_final_se(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);

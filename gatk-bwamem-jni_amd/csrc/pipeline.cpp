@@ -365,6 +365,7 @@ static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes
             }
             TIMED(ws, K_SA, launch_sa(ws.stream, ix->d, opt, tv, n_occ));
             TIMED(ws, K_CHAIN, launch_chain(ws.stream, ix->d, opt, tv, ws.chain_store.as<Chain>()));
+        TIMED(ws, K_CHAIN, launch_rescore(ws.stream, ix->d, opt, tv));
             TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
             TIMED(ws, K_POST, launch_post1(ws.stream, ix->d, opt, tv));
             PeTile* pt = new PeTile(); tiles.push_back(pt);
@@ -521,6 +522,7 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
         }
         TIMED(ws, K_SA, launch_sa(ws.stream, ix->d, opt, tv, n_occ));
         TIMED(ws, K_CHAIN, launch_chain(ws.stream, ix->d, opt, tv, ws.chain_store.as<Chain>()));
+        TIMED(ws, K_CHAIN, launch_rescore(ws.stream, ix->d, opt, tv));
         TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
         if (getenv("BWAMEM_HIP_DUMP") && T <= 64) debug_dump(ws, tv, T);
         TIMED(ws, K_POST, launch_post1(ws.stream, ix->d, opt, tv));

@@ -64,3 +64,10 @@ def test_emu_concurrent_tiles(emu, oracle, small_genome, monkeypatch):
     monkeypatch.setenv("BWAMEM_HIP_TILE", "7")
     monkeypatch.setenv("BWAMEM_HIP_STREAMS", "3")
     _cmp(emu, oracle, img, reads)
+
+
+def test_emu_long_reads_seed_rescoring(emu, oracle, small_genome):
+    """reads long enough (5.5 ln L <= 0.05 L) to go through mem_flt_chained_seeds / mem_seed_sw (row a10)"""
+    seqs, img = small_genome
+    reads = B.simulate_reads(seqs, 2, length=800, seed=5, sub=0.06, indel=0.02)
+    _cmp(emu, oracle, img, reads)

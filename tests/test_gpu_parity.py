@@ -220,3 +220,12 @@ def test_pe_multi_tile(hip_lib, oracle, small_genome, monkeypatch):
     whole = _parity_pe(hip_lib, oracle, img, pairs)
     monkeypatch.setenv("BWAMEM_HIP_TILE", "90")
     assert _parity_pe(hip_lib, oracle, img, pairs) == whole
+
+
+def test_parity_long_reads(hip_lib, oracle, medium_genome):
+    """config-5 style reads: seed re-scoring (row a10), wide bands, long chains, big global alignments"""
+    seqs, img = medium_genome
+    reads = B.simulate_reads(seqs, 150, length=1000, seed=5, sub=0.06, indel=0.02, random_frac=0.0)
+    reads += B.simulate_reads(seqs, 40, length=3000, seed=6, sub=0.08, indel=0.03, random_frac=0.0)
+    reads += B.simulate_reads(seqs, 6, length=10000, seed=7, sub=0.08, indel=0.06, random_frac=0.0)
+    _parity(hip_lib, oracle, img, reads)
