@@ -8,6 +8,7 @@
 // CU, not from parallelism inside a read.
 #include "dev_common.h"
 #include "kernels.h"
+#include "wave_ops.h"
 
 // Per-read interval vectors live in global scratch laid out [entry][lane]: when the 64 reads of a wave push or
 // read entry e together, the wave touches one contiguous 2 KB span instead of 64 scattered lines.
@@ -21,88 +22,6 @@ struct IntvVec {
 DEV void vec_reverse(IntvVec& v, int from = 0)
 {
     for (int i = from, j = v.n - 1; i < j; ++i, --j) { Intv t = v.get(i); v.set(i, v.get(j)); v.set(j, t); }
-}
-
-// all SMEMs through position x with interval size >= min_intv, appended to mem when at least min_seed_len long
-// (the caller's filter, fused so no intermediate vector is needed); returns the next x.
-// Forward-extend recording each size change, then backward-extend every candidate in lock-step,
-// longest first (App. B "SMEM(x, min_intv)").
-DEV int smem1(const DevIndex& ix, int len, const uint8_t* q, int x, int min_intv, int min_seed_len,
-              IntvVec& mem, IntvVec& v0, IntvVec& v1, uint32_t& n_ext, bool& ovf)
-{
-    Intv ik, ok;
-    IntvVec *prev = &v0, *curr = &v1, *swap;
-    int i, j, c;
-    const int mem0 = mem.n;
-    uint64_t last_start = ~0ull;                 // start of the most recently emitted match (before the length filter)
-    bool any = false;
-    if (q[x] > 3) return x + 1;
-    if (min_intv < 1) min_intv = 1;
-    set_intv(ix, q[x], ik);
-    ik.info = (uint64_t)(x + 1);
-    for (i = x + 1, curr->n = 0; i < len; ++i) {
-        if (q[i] < 4) {
-            c = 3 - q[i];
-            ok = extend_one(ix, ik, c, 0); ++n_ext;
-            if (ok.size != ik.size) {
-                if (!curr->push(ik)) { ovf = true; return len; }
-                if (ok.size < (uint64_t)min_intv) break;
-            }
-            ik = ok; ik.info = (uint64_t)(i + 1);
-        } else {
-            if (!curr->push(ik)) { ovf = true; return len; }
-            break;
-        }
-    }
-    if (i == len) { if (!curr->push(ik)) { ovf = true; return len; } }
-    vec_reverse(*curr);
-    int ret = (int)curr->get(0).info;
-    swap = curr; curr = prev; prev = swap;
-    for (i = x - 1; i >= -1; --i) {
-        c = i < 0 ? -1 : q[i] < 4 ? q[i] : -1;
-        for (j = 0, curr->n = 0; j < prev->n; ++j) {
-            Intv p = prev->get(j);
-            if (c >= 0) { ok = extend_one(ix, p, c, 1); ++n_ext; }
-            if (c < 0 || ok.size < (uint64_t)min_intv) {
-                if (curr->n == 0) {
-                    if (!any || (uint64_t)(i + 1) < last_start) {
-                        any = true; last_start = (uint64_t)(i + 1);
-                        ik = p; ik.info |= (uint64_t)(i + 1) << 32;
-                        if ((int)((uint32_t)ik.info - (uint32_t)(ik.info >> 32)) >= min_seed_len) { if (!mem.push(ik)) { ovf = true; return len; } }
-                    }
-                }
-            } else if (curr->n == 0 || ok.size != curr->get(curr->n - 1).size) {
-                ok.info = p.info;
-                if (!curr->push(ok)) { ovf = true; return len; }
-            }
-        }
-        if (curr->n == 0) break;
-        swap = curr; curr = prev; prev = swap;
-    }
-    vec_reverse(mem, mem0);                       // this call's matches in order of start
-    return ret;
-}
-
-// pass 3: greedy forward seed (row a5)
-DEV int seed_strategy1(const DevIndex& ix, int len, const uint8_t* q, int x, int min_len, int max_intv, Intv& mem, uint32_t& n_ext)
-{
-    Intv ik, ok;
-    mem.x0 = mem.x1 = mem.size = mem.info = 0;
-    if (q[x] > 3) return x + 1;
-    set_intv(ix, q[x], ik);
-    for (int i = x + 1; i < len; ++i) {
-        if (q[i] < 4) {
-            int c = 3 - q[i];
-            ok = extend_one(ix, ik, c, 0); ++n_ext;
-            if (ok.size < (uint64_t)(int64_t)max_intv && i - x >= min_len) {
-                mem = ok;
-                mem.info = (uint64_t)x << 32 | (uint32_t)(i + 1);
-                return i + 1;
-            }
-            ik = ok;
-        } else return i + 1;
-    }
-    return len;
 }
 
 // ASCII -> 0..4 in place (upstream nst_nt4_table; bytes < 4 are kept as they are)
@@ -120,74 +39,186 @@ __global__ void k_encode(uint8_t* seq, int64_t n_bytes)
     }
 }
 
-// mem_collect_intv (row a6) + the per-read bookkeeping mem_chain does before looking up the SA:
-// l_rep (repetitive fraction numerator) and the number of occurrences each interval contributes.
+// mem_collect_intv (row a6): three seeding passes, written as a per-lane state machine.
+//
+// Upstream's control flow is four nested data-dependent loops per read.  Run naively one-read-per-lane, the
+// lanes of a wave sit in different loops most of the time and the wave executes each lane's interval
+// extensions almost serially (PMC: ~10 k extend steps per wave for ~860 per read).  Here every iteration of
+// ONE wave-level loop performs exactly one interval extension per lane -- the expensive part: two dependent
+// 64-byte occ gathers plus the popcounts -- and all bookkeeping between two extensions is cheap per-lane
+// state transitions.  The sequence of extensions and pushes of each read is exactly upstream's
+// (bwt_smem1 / bwt_seed_strategy1 / mem_collect_intv), so the resulting interval list is identical.
+enum { ST_NEXT = 0, ST_FWD = 1, ST_BWD = 2, ST_P3 = 3, ST_DONE = 4 };
+
 __global__ void k_seed(DevIndex ix, MemOpt opt, TileView tv)
 {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = r < tv.n_reads;
+    const int rr = in_range ? r : 0;
     uint32_t n_ext = 0;
-    if (r < tv.n_reads) {
-        const uint8_t* q = tv.seq + tv.seq_off[r];
-        int len = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
-        // scratch of wave-group g = r/64: [2 vectors][smem_cap entries][64 lanes]
-        Intv* sc = tv.smem_scratch + ((size_t)(r >> 6) * 2 * tv.smem_cap) * 64 + (r & 63);
-        IntvVec v0 = { sc, 0, tv.smem_cap, 64 };
-        IntvVec v1 = { sc + (size_t)tv.smem_cap * 64, 0, tv.smem_cap, 64 };
-        IntvVec mem = { tv.intv + (size_t)r * tv.intv_cap, 0, tv.intv_cap, 1 };
-        bool ovf = false;
-        int n_seeds = 0, l_rep = 0;
-        if (len >= opt.min_seed_len) {
-            int x = 0;
-            int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
-            while (x < len && !ovf) {                       // pass 1: all SMEMs
-                if (q[x] < 4) x = smem1(ix, len, q, x, 1, opt.min_seed_len, mem, v0, v1, n_ext, ovf);
-                else ++x;
-            }
-            int old_n = mem.n;
-            for (int k = 0; k < old_n && !ovf; ++k) {       // pass 2: re-seed long, rare SMEMs
-                Intv p = mem.get(k);
-                int start = (int)(p.info >> 32), end = (int)(int32_t)p.info;
-                if (end - start < split_len || p.size > (uint64_t)(int64_t)opt.split_width) continue;
-                smem1(ix, len, q, (start + end) >> 1, (int)(p.size + 1), opt.min_seed_len, mem, v0, v1, n_ext, ovf);
-            }
-            if (opt.max_mem_intv > 0) {                     // pass 3: greedy forward seeds
-                x = 0;
-                while (x < len && !ovf) {
-                    if (q[x] < 4) {
-                        Intv m;
-                        x = seed_strategy1(ix, len, q, x, opt.min_seed_len, (int)opt.max_mem_intv, m, n_ext);
-                        if (m.size > 0) { if (!mem.push(m)) ovf = true; }
-                    } else ++x;
-                }
-            }
-            if (!ovf) {
-                // sort by info.  Intervals with equal info are the same substring, hence identical records, so the
-                // order upstream's unstable sort leaves them in is unobservable: a plain insertion sort suffices.
-                for (int i = 1; i < mem.n; ++i) {
-                    Intv t = mem.a[i];
-                    int j = i;
-                    while (j > 0 && mem.a[j - 1].info > t.info) { mem.a[j] = mem.a[j - 1]; --j; }
-                    mem.a[j] = t;
-                }
-                int b = 0, e = 0;
-                int32_t* iso = tv.intv_seed_off + (size_t)r * tv.intv_cap;
-                for (int i = 0; i < mem.n; ++i) {
-                    Intv p = mem.a[i];
-                    int sb = (int)(p.info >> 32), se = (int)(uint32_t)p.info;
-                    iso[i] = n_seeds;
-                    {
-                        int64_t step = p.size > (uint64_t)(int64_t)opt.max_occ ? (int64_t)(p.size / (uint64_t)opt.max_occ) : 1;
-                        int64_t c = ((int64_t)p.size + step - 1) / step;
-                        n_seeds += (int)(c < opt.max_occ ? c : opt.max_occ);
+    const uint8_t* q = tv.seq + tv.seq_off[rr];
+    const int len = (int)(tv.seq_off[rr + 1] - tv.seq_off[rr] - 1);
+    // scratch of wave-group g = r/64: [2 vectors][smem_cap entries][64 lanes]
+    Intv* sc = tv.smem_scratch + ((size_t)(rr >> 6) * 2 * tv.smem_cap) * 64 + (rr & 63);
+    IntvVec vv[2] = { { sc, 0, tv.smem_cap, 64 }, { sc + (size_t)tv.smem_cap * 64, 0, tv.smem_cap, 64 } };
+    IntvVec mem = { tv.intv + (size_t)rr * tv.intv_cap, 0, tv.intv_cap, 1 };
+    const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
+    const int min_seed_len = opt.min_seed_len;
+
+    int st = (in_range && len >= min_seed_len) ? ST_NEXT : ST_DONE;
+    int pass = 1, x = 0, i = 0, j = 0, c = 0, sx = 0, min_intv = 1, ret = 0, k2 = 0, old_n = 0, mem0 = 0;
+    int pv = 0;                         // vv[pv] = prev, vv[pv ^ 1] = curr
+    bool any = false, ovf = false, row_start = false;
+    uint64_t last_start = 0, last_curr_size = 0;
+    Intv ik, req, ok;
+    ik.x0 = ik.x1 = ik.size = ik.info = 0; req = ik; ok = ik;
+
+    while (wave_any(st != ST_DONE)) {
+        bool need = false;
+        int is_back = 0;
+        // ---- (a) per-lane transitions until this lane needs an interval extension
+        while (st != ST_DONE && !need) {
+            if (ovf) { st = ST_DONE; break; }
+            if (st == ST_NEXT) {
+                int nx = -1, nmin = 1;
+                if (pass == 1) {
+                    while (x < len && q[x] > 3) ++x;
+                    if (x < len) { nx = x; nmin = 1; }
+                    else { pass = 2; old_n = mem.n; k2 = 0; }
+                } else if (pass == 2) {
+                    while (k2 < old_n) {
+                        Intv p = mem.get(k2);
+                        int s0 = (int)(p.info >> 32), e0 = (int)(int32_t)p.info;
+                        if (e0 - s0 < split_len || p.size > (uint64_t)(int64_t)opt.split_width) { ++k2; continue; }
+                        nx = (s0 + e0) >> 1; nmin = (int)(p.size + 1);
+                        break;
                     }
-                    if (p.size <= (uint64_t)(int64_t)opt.max_occ) continue;
-                    if (sb > e) { l_rep += e - b; b = sb; e = se; }
-                    else e = e > se ? e : se;
+                    if (nx < 0) { pass = 3; x = 0; }
+                    else if (q[nx] > 3) { ++k2; nx = -1; }          // bwt_smem1 returns at once on an ambiguous base
+                } else {
+                    if (!(opt.max_mem_intv > 0)) { st = ST_DONE; }
+                    else {
+                        while (x < len && q[x] > 3) ++x;
+                        if (x >= len) st = ST_DONE;
+                        else { set_intv(ix, q[x], ik); sx = x; i = x + 1; st = ST_P3; }
+                    }
                 }
-                l_rep += e - b;
+                if (nx >= 0) {                                       // enter bwt_smem1(nx, nmin)
+                    sx = nx; min_intv = nmin < 1 ? 1 : nmin;
+                    set_intv(ix, q[sx], ik);
+                    ik.info = (uint64_t)(sx + 1);
+                    i = sx + 1; vv[pv ^ 1].n = 0; mem0 = mem.n; any = false;
+                    st = ST_FWD;
+                }
+            } else if (st == ST_FWD) {
+                bool end_fwd = false;
+                if (i < len) {
+                    if (q[i] < 4) { req = ik; c = 3 - q[i]; is_back = 0; need = true; }
+                    else { if (!vv[pv ^ 1].push(ik)) ovf = true; end_fwd = true; }
+                } else { if (!vv[pv ^ 1].push(ik)) ovf = true; end_fwd = true; }
+                if (end_fwd && !ovf) {                               // longest match first, then walk backwards
+                    vec_reverse(vv[pv ^ 1]);
+                    ret = (int)vv[pv ^ 1].get(0).info;
+                    pv ^= 1;
+                    i = sx - 1; j = 0; row_start = true;
+                    st = ST_BWD;
+                }
+            } else if (st == ST_BWD) {
+                if (row_start) { c = i < 0 ? -1 : (q[i] < 4 ? q[i] : -1); vv[pv ^ 1].n = 0; row_start = false; }
+                if (j < vv[pv].n) {
+                    req = vv[pv].get(j);
+                    if (c >= 0) { is_back = 1; need = true; }
+                    else {                                           // start of the read or an ambiguous base: every candidate ends here
+                        if (vv[pv ^ 1].n == 0 && (!any || (uint64_t)(i + 1) < last_start)) {
+                            any = true; last_start = (uint64_t)(i + 1);
+                            Intv m = req; m.info |= (uint64_t)(i + 1) << 32;
+                            if ((int)((uint32_t)m.info - (uint32_t)(m.info >> 32)) >= min_seed_len) { if (!mem.push(m)) ovf = true; }
+                        }
+                        ++j;
+                    }
+                } else if (vv[pv ^ 1].n == 0) {                      // no candidate survived: this bwt_smem1 call is complete
+                    vec_reverse(mem, mem0);
+                    if (pass == 1) x = ret; else ++k2;
+                    st = ST_NEXT;
+                } else { pv ^= 1; --i; j = 0; row_start = true; }
+            } else {                                                 // ST_P3: bwt_seed_strategy1
+                if (i < len) {
+                    if (q[i] < 4) { req = ik; c = 3 - q[i]; is_back = 0; need = true; }
+                    else { x = i + 1; st = ST_NEXT; }
+                } else { x = len; st = ST_NEXT; }
             }
         }
-        if (ovf) { atomicOr(tv.err, ERR_INTV_CAP); mem.n = 0; n_seeds = 0; l_rep = 0; }
+        // ---- (b) one interval extension per lane, executed by the whole wave together
+        if (need) { ok = extend_one(ix, req, c, is_back); ++n_ext; }
+        // ---- (c) consume the result
+        if (need) {
+            if (st == ST_FWD) {
+                bool stop = false;
+                if (ok.size != ik.size) {
+                    if (!vv[pv ^ 1].push(ik)) ovf = true;
+                    if (ok.size < (uint64_t)min_intv) stop = true;
+                }
+                if (stop) {                                          // upstream breaks with i < len: no final push
+                    if (!ovf) {
+                        vec_reverse(vv[pv ^ 1]);
+                        ret = (int)vv[pv ^ 1].get(0).info;
+                        pv ^= 1;
+                        i = sx - 1; j = 0; row_start = true;
+                        st = ST_BWD;
+                    }
+                } else { ik = ok; ik.info = (uint64_t)(i + 1); ++i; }
+            } else if (st == ST_BWD) {
+                if (ok.size < (uint64_t)min_intv) {
+                    if (vv[pv ^ 1].n == 0 && (!any || (uint64_t)(i + 1) < last_start)) {
+                        any = true; last_start = (uint64_t)(i + 1);
+                        Intv m = req; m.info |= (uint64_t)(i + 1) << 32;
+                        if ((int)((uint32_t)m.info - (uint32_t)(m.info >> 32)) >= min_seed_len) { if (!mem.push(m)) ovf = true; }
+                    }
+                } else if (vv[pv ^ 1].n == 0 || ok.size != last_curr_size) {
+                    ok.info = req.info;
+                    if (!vv[pv ^ 1].push(ok)) ovf = true;
+                    last_curr_size = ok.size;
+                }
+                ++j;
+            } else {                                                 // ST_P3
+                if (ok.size < (uint64_t)(int64_t)(int)opt.max_mem_intv && i - sx >= min_seed_len) {
+                    Intv m = ok;
+                    m.info = (uint64_t)sx << 32 | (uint32_t)(i + 1);
+                    if (m.size > 0) { if (!mem.push(m)) ovf = true; }
+                    x = i + 1; st = ST_NEXT;
+                } else { ik = ok; ++i; }
+            }
+        }
+    }
+
+    if (in_range) {
+        int n_seeds = 0, l_rep = 0;
+        if (!ovf) {
+            // sort by info.  Intervals with equal info are the same substring, hence identical records, so the
+            // order upstream's unstable sort leaves them in is unobservable: a plain insertion sort suffices.
+            for (int a = 1; a < mem.n; ++a) {
+                Intv t = mem.a[a];
+                int b = a;
+                while (b > 0 && mem.a[b - 1].info > t.info) { mem.a[b] = mem.a[b - 1]; --b; }
+                mem.a[b] = t;
+            }
+            int b = 0, e = 0;
+            int32_t* iso = tv.intv_seed_off + (size_t)r * tv.intv_cap;
+            for (int a = 0; a < mem.n; ++a) {
+                Intv p = mem.a[a];
+                int sb = (int)(p.info >> 32), se = (int)(uint32_t)p.info;
+                iso[a] = n_seeds;
+                {
+                    int64_t step = p.size > (uint64_t)(int64_t)opt.max_occ ? (int64_t)(p.size / (uint64_t)opt.max_occ) : 1;
+                    int64_t cc = ((int64_t)p.size + step - 1) / step;
+                    n_seeds += (int)(cc < opt.max_occ ? cc : opt.max_occ);
+                }
+                if (p.size <= (uint64_t)(int64_t)opt.max_occ) continue;
+                if (sb > e) { l_rep += e - b; b = sb; e = se; }
+                else e = e > se ? e : se;
+            }
+            l_rep += e - b;
+        } else { atomicOr(tv.err, ERR_INTV_CAP); mem.n = 0; }
         tv.n_intv[r] = mem.n;
         tv.n_seeds[r] = n_seeds;
         tv.l_rep[r] = l_rep;

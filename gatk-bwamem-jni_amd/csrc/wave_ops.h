@@ -26,3 +26,5 @@ static __device__ inline int wave_max(int v)
 static __device__ inline int wave_bcast(int v, int src) { return __shfl(v, src); }
 
 static __device__ inline unsigned long long wave_ballot(int pred) { return __ballot(pred); }
+
+static __device__ inline bool wave_any(int pred) { return __ballot(pred) != 0ull; }
