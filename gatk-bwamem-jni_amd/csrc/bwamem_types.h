@@ -101,7 +101,7 @@ struct DevCounters {
 };
 
 // per-tile error / overflow flags set by kernels, read back by the host after each stage
-enum { ERR_INTV_CAP = 1, ERR_OUT_CAP = 2, ERR_CIGAR_CAP = 4, ERR_LONG_READ = 8, ERR_SCRATCH = 16, ERR_BTREE = 32, ERR_BAD_REG = 64 };
+enum { ERR_INTV_CAP = 1, ERR_OUT_CAP = 2, ERR_CIGAR_CAP = 4, ERR_LONG_READ = 8, ERR_SCRATCH = 16, ERR_BTREE = 32, ERR_BAD_REG = 64, ERR_JOB_CAP = 128, ERR_ZPOOL = 256 };
 
 struct TileView {
     // reads of this tile
@@ -141,6 +141,10 @@ struct TileView {
     // flags + counters
     int32_t* err;
     DevCounters* cnt;
+    // global-alignment jobs (single-end): regions whose CIGAR needs DP, compacted for the wave-parallel kernel
+    int32_t* job_cnt;             // [1]
+    void* jobs;                   // DpJob[job_cap]
+    int32_t job_cap, pad2_;
     int32_t debug;                // BWAMEM_HIP_DEBUGK: device-side progress prints (debugging aid)
     int32_t pad_;
 };

@@ -40,7 +40,44 @@ __global__ void k_post1(DevIndex ix, MemOpt opt, TileView tv)
 }
 
 // ------------------------------------------------------------------ single-end finalisation
-__global__ void k_final_se(DevIndex ix, MemOpt opt, TileView tv)
+// step 1: primary marking, and a job for every region whose record (or XA entry) needs a banded global alignment
+__global__ void k_final_prep(DevIndex ix, MemOpt opt, TileView tv)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= tv.n_reads) return;
+    AlnReg* a = tv.regs + tv.seed_off[r];
+    const int n = tv.n_regs[r];
+    int32_t* zbuf = (int32_t*)(tv.srt + tv.seed_off[r]);      // >= 2 ints per region
+    mark_primary_se(opt, n, a, tv.read_id0 + r, zbuf);
+    if (opt.flag & MEM_F_PRIMARY5) reorder_primary5(opt.T, n, a);
+    int32_t *cnt = 0, *has_alt = 0;
+    if (!(opt.flag & MEM_F_ALL) && n > 0) {
+        cnt = zbuf; has_alt = zbuf + n;
+        if (xa_prepare(opt, n, a, cnt, has_alt) == 0) cnt = has_alt = 0;
+    }
+    DpJob* jobs = (DpJob*)tv.jobs;
+    for (int k = 0; k < n; ++k) {
+        AlnReg* p = &a[k];
+        p->pad_ = 0;
+        // will mem_reg2sam emit a record for it?
+        bool rec = !(p->score < opt.T) && !(p->secondary >= 0 && (p->is_alt || !(opt.flag & MEM_F_ALL)))
+                && !(p->secondary >= 0 && p->secondary < INT_MAX_ && (float)p->score < (float)a[p->secondary].score * opt.drop_ratio);
+        // will mem_gen_alt list it in an XA tag?
+        bool xa = false;
+        if (cnt) {
+            int pr = get_pri_idx(opt.XA_drop_ratio, a, k);
+            xa = pr >= 0 && !(cnt[pr] > opt.max_XA_hits_alt || (!has_alt[pr] && cnt[pr] > opt.max_XA_hits));
+        }
+        if ((rec || xa) && region_needs_dp(opt, *p)) {
+            int job = atomicAdd(tv.job_cnt, 1);
+            if (job < tv.job_cap) { DpJob jb; jb.read = r; jb.reg = k; jobs[job] = jb; p->pad_ = job + 1; }
+            else atomicOr(tv.err, ERR_JOB_CAP);
+        }
+    }
+}
+
+// step 3 (after k_gcigar): mem_reg2sam record selection and the reference's fmt_BAMish record writer
+__global__ void k_final_se(DevIndex ix, MemOpt opt, TileView tv, JobView jv)
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= tv.n_reads) return;
@@ -49,12 +86,10 @@ __global__ void k_final_se(DevIndex ix, MemOpt opt, TileView tv)
     int l_query = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
     AlnReg* a = tv.regs + tv.seed_off[r];
     int n = tv.n_regs[r];
-    int32_t* zbuf = (int32_t*)(tv.srt + tv.seed_off[r]);      // >= 2 ints per region
+    int32_t* zbuf = (int32_t*)(tv.srt + tv.seed_off[r]);
     OutBuf ob; ob.p = tv.out + (size_t)r * tv.out_cap; ob.cap = tv.out_cap; ob.len = 0; ob.ovf = false;
 
-    mark_primary_se(opt, n, a, tv.read_id0 + r, zbuf);
-    if (opt.flag & MEM_F_PRIMARY5) reorder_primary5(opt.T, n, a);
-    reg2sam(ix, opt, S, ob, l_query, query, n, a, zbuf, 0, (const MateInfo*)0);
+    reg2sam(ix, opt, S, ob, l_query, query, n, a, zbuf, 0, (const MateInfo*)0, &jv);
 
     tv.out_len[r] = ob.ovf ? 0 : ob.len;
     if (ob.ovf) atomicOr(tv.err, ERR_OUT_CAP);
@@ -78,10 +113,16 @@ void launch_post1(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const T
     if (tv.n_reads <= 0) return;
     hipLaunchKernelGGL(k_post1, dim3((tv.n_reads + 63) / 64), dim3(64), 0, st, ix, opt, tv);
 }
-void launch_final_se(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv)
+void launch_final_prep(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv)
 {
     if (tv.n_reads <= 0) return;
-    hipLaunchKernelGGL(k_final_se, dim3((tv.n_reads + 63) / 64), dim3(64), 0, st, ix, opt, tv);
+    hipLaunchKernelGGL(k_final_prep, dim3((tv.n_reads + 63) / 64), dim3(64), 0, st, ix, opt, tv);
+}
+void launch_final_se(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, const void* job_out, const uint32_t* job_cig, int cig_cap)
+{
+    if (tv.n_reads <= 0) return;
+    JobView jv; jv.out = (const DpOut*)job_out; jv.cig = job_cig; jv.cig_cap = cig_cap;
+    hipLaunchKernelGGL(k_final_se, dim3((tv.n_reads + 63) / 64), dim3(64), 0, st, ix, opt, tv, jv);
 }
 void launch_pack(hipStream_t st, const TileView& tv, uint8_t* dst)
 {

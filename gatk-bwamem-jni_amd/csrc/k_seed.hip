@@ -60,14 +60,25 @@ __global__ void k_seed(DevIndex ix, MemOpt opt, TileView tv)
     const int len = (int)(tv.seq_off[rr + 1] - tv.seq_off[rr] - 1);
     // scratch of wave-group g = r/64: [2 vectors][smem_cap entries][64 lanes]
     Intv* sc = tv.smem_scratch + ((size_t)(rr >> 6) * 2 * tv.smem_cap) * 64 + (rr & 63);
-    IntvVec vv[2] = { { sc, 0, tv.smem_cap, 64 }, { sc + (size_t)tv.smem_cap * 64, 0, tv.smem_cap, 64 } };
+    // prev / curr candidate vectors: two lane-interleaved arrays whose roles swap; kept as plain registers
+    // (an array indexed by the role bit would live in private scratch memory)
+    Intv* const pa = sc; Intv* const pb = sc + (size_t)tv.smem_cap * 64;
+    const int vcap = tv.smem_cap;
+    int na = 0, nb = 0;
+#define PREV_PTR (pv ? pb : pa)
+#define CURR_PTR (pv ? pa : pb)
+#define PREV_N (pv ? nb : na)
+#define CURR_N (pv ? na : nb)
+#define SET_CURR_N(v) do { if (pv) na = (v); else nb = (v); } while (0)
+#define CURR_PUSH(val) do { int n_ = CURR_N; if (n_ >= vcap) ovf = true; else { CURR_PTR[(size_t)n_ * 64] = (val); SET_CURR_N(n_ + 1); } } while (0)
+#define CURR_REVERSE() do { Intv* p_ = CURR_PTR; for (int a_ = 0, b_ = CURR_N - 1; a_ < b_; ++a_, --b_) { Intv t_ = p_[(size_t)a_ * 64]; p_[(size_t)a_ * 64] = p_[(size_t)b_ * 64]; p_[(size_t)b_ * 64] = t_; } } while (0)
     IntvVec mem = { tv.intv + (size_t)rr * tv.intv_cap, 0, tv.intv_cap, 1 };
     const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
     const int min_seed_len = opt.min_seed_len;
 
     int st = (in_range && len >= min_seed_len) ? ST_NEXT : ST_DONE;
     int pass = 1, x = 0, i = 0, j = 0, c = 0, sx = 0, min_intv = 1, ret = 0, k2 = 0, old_n = 0, mem0 = 0;
-    int pv = 0;                         // vv[pv] = prev, vv[pv ^ 1] = curr
+    int pv = 0;                         // role bit: pv = 0 -> pa is prev, pb is curr
     bool any = false, ovf = false, row_start = false;
     uint64_t last_start = 0, last_curr_size = 0;
     Intv ik, req, ok;
@@ -107,36 +118,36 @@ __global__ void k_seed(DevIndex ix, MemOpt opt, TileView tv)
                     sx = nx; min_intv = nmin < 1 ? 1 : nmin;
                     set_intv(ix, q[sx], ik);
                     ik.info = (uint64_t)(sx + 1);
-                    i = sx + 1; vv[pv ^ 1].n = 0; mem0 = mem.n; any = false;
+                    i = sx + 1; SET_CURR_N(0); mem0 = mem.n; any = false;
                     st = ST_FWD;
                 }
             } else if (st == ST_FWD) {
                 bool end_fwd = false;
                 if (i < len) {
                     if (q[i] < 4) { req = ik; c = 3 - q[i]; is_back = 0; need = true; }
-                    else { if (!vv[pv ^ 1].push(ik)) ovf = true; end_fwd = true; }
-                } else { if (!vv[pv ^ 1].push(ik)) ovf = true; end_fwd = true; }
+                    else { CURR_PUSH(ik); end_fwd = true; }
+                } else { CURR_PUSH(ik); end_fwd = true; }
                 if (end_fwd && !ovf) {                               // longest match first, then walk backwards
-                    vec_reverse(vv[pv ^ 1]);
-                    ret = (int)vv[pv ^ 1].get(0).info;
+                    CURR_REVERSE();
+                    ret = (int)CURR_PTR[0].info;
                     pv ^= 1;
                     i = sx - 1; j = 0; row_start = true;
                     st = ST_BWD;
                 }
             } else if (st == ST_BWD) {
-                if (row_start) { c = i < 0 ? -1 : (q[i] < 4 ? q[i] : -1); vv[pv ^ 1].n = 0; row_start = false; }
-                if (j < vv[pv].n) {
-                    req = vv[pv].get(j);
+                if (row_start) { c = i < 0 ? -1 : (q[i] < 4 ? q[i] : -1); SET_CURR_N(0); row_start = false; }
+                if (j < PREV_N) {
+                    req = PREV_PTR[(size_t)j * 64];
                     if (c >= 0) { is_back = 1; need = true; }
                     else {                                           // start of the read or an ambiguous base: every candidate ends here
-                        if (vv[pv ^ 1].n == 0 && (!any || (uint64_t)(i + 1) < last_start)) {
+                        if (CURR_N == 0 && (!any || (uint64_t)(i + 1) < last_start)) {
                             any = true; last_start = (uint64_t)(i + 1);
                             Intv m = req; m.info |= (uint64_t)(i + 1) << 32;
                             if ((int)((uint32_t)m.info - (uint32_t)(m.info >> 32)) >= min_seed_len) { if (!mem.push(m)) ovf = true; }
                         }
                         ++j;
                     }
-                } else if (vv[pv ^ 1].n == 0) {                      // no candidate survived: this bwt_smem1 call is complete
+                } else if (CURR_N == 0) {                            // no candidate survived: this bwt_smem1 call is complete
                     vec_reverse(mem, mem0);
                     if (pass == 1) x = ret; else ++k2;
                     st = ST_NEXT;
@@ -155,13 +166,13 @@ __global__ void k_seed(DevIndex ix, MemOpt opt, TileView tv)
             if (st == ST_FWD) {
                 bool stop = false;
                 if (ok.size != ik.size) {
-                    if (!vv[pv ^ 1].push(ik)) ovf = true;
+                    CURR_PUSH(ik);
                     if (ok.size < (uint64_t)min_intv) stop = true;
                 }
                 if (stop) {                                          // upstream breaks with i < len: no final push
                     if (!ovf) {
-                        vec_reverse(vv[pv ^ 1]);
-                        ret = (int)vv[pv ^ 1].get(0).info;
+                        CURR_REVERSE();
+                        ret = (int)CURR_PTR[0].info;
                         pv ^= 1;
                         i = sx - 1; j = 0; row_start = true;
                         st = ST_BWD;
@@ -169,14 +180,14 @@ __global__ void k_seed(DevIndex ix, MemOpt opt, TileView tv)
                 } else { ik = ok; ik.info = (uint64_t)(i + 1); ++i; }
             } else if (st == ST_BWD) {
                 if (ok.size < (uint64_t)min_intv) {
-                    if (vv[pv ^ 1].n == 0 && (!any || (uint64_t)(i + 1) < last_start)) {
+                    if (CURR_N == 0 && (!any || (uint64_t)(i + 1) < last_start)) {
                         any = true; last_start = (uint64_t)(i + 1);
                         Intv m = req; m.info |= (uint64_t)(i + 1) << 32;
                         if ((int)((uint32_t)m.info - (uint32_t)(m.info >> 32)) >= min_seed_len) { if (!mem.push(m)) ovf = true; }
                     }
-                } else if (vv[pv ^ 1].n == 0 || ok.size != last_curr_size) {
+                } else if (CURR_N == 0 || ok.size != last_curr_size) {
                     ok.info = req.info;
-                    if (!vv[pv ^ 1].push(ok)) ovf = true;
+                    CURR_PUSH(ok);
                     last_curr_size = ok.size;
                 }
                 ++j;

@@ -11,7 +11,10 @@ void launch_chain(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const T
 void launch_rescore(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 void launch_extend(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 void launch_post1(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
-void launch_final_se(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
+void launch_final_prep(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
+void launch_gcigar(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, int n_jobs, const void* jobs, void* outs, uint32_t* cig_pool, int cig_cap,
+                   uint8_t* zpool, unsigned long long zpool_cap, unsigned long long* zpool_cur);
+void launch_final_se(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, const void* job_out, const uint32_t* job_cig, int cig_cap);
 void launch_pack(hipStream_t st, const TileView& tv, uint8_t* dst);
 
 // paired-end path (k_pe.hip)

@@ -65,6 +65,8 @@ struct Workspace {
     DevBuf intv, n_intv, smem, l_rep, n_seeds, seed_off, intv_seed_off;
     DevBuf seeds, seed_rid, cseeds, chains, chain_store, n_chains, bt_nodes, srt, regs, n_regs;
     DevBuf out, out_len, out_off, post, err, cnt;
+    DevBuf jobs, job_out, job_cig, job_cnt, zpool;   // single-end global-alignment jobs
+    int job_cap = 0, job_cig_cap = 0; size_t zpool_cap = 0;
     hipStream_t stream = nullptr;
     std::vector<Timed> timed;
 
@@ -76,6 +78,11 @@ struct Workspace {
             && n_chains.ensure(t * 4) && n_regs.ensure(t * 4) && out.ensure(t * out_cap) && out_len.ensure(t * 4)
             && out_off.ensure((t + 1) * 8) && post.ensure(t * (size_t)post_per_read) && err.ensure(64) && cnt.ensure(sizeof(DevCounters));
     }
+    bool ensure_jobs(int n_jobs, int cig_cap_, size_t zpool_bytes) {
+        job_cap = std::max(job_cap, n_jobs); job_cig_cap = cig_cap_; zpool_cap = std::max(zpool_cap, zpool_bytes);
+        return jobs.ensure((size_t)job_cap * 8) && job_out.ensure((size_t)job_cap * 8) && job_cig.ensure((size_t)job_cap * job_cig_cap * 4)
+            && job_cnt.ensure(64) && zpool.ensure(zpool_cap);
+    }
     bool ensure_seeds(int64_t n) {
         seed_cap = n;
         size_t s = (size_t)n + 16;
@@ -85,7 +92,8 @@ struct Workspace {
     }
     void release() {
         DevBuf* all[] = { &intv, &n_intv, &smem, &l_rep, &n_seeds, &seed_off, &intv_seed_off, &seeds, &seed_rid, &cseeds, &chains,
-                          &chain_store, &n_chains, &bt_nodes, &srt, &regs, &n_regs, &out, &out_len, &out_off, &post, &err, &cnt };
+                          &chain_store, &n_chains, &bt_nodes, &srt, &regs, &n_regs, &out, &out_len, &out_off, &post, &err, &cnt,
+                          &jobs, &job_out, &job_cig, &job_cnt, &zpool };
         for (DevBuf* b : all) b->release();
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     }
@@ -100,6 +108,7 @@ struct Workspace {
         tv.out_cap = out_cap; tv.out = out.as<uint8_t>(); tv.out_len = out_len.as<int32_t>(); tv.out_off = out_off.as<int64_t>();
         tv.post_scratch = post.as<uint8_t>(); tv.post_scratch_per_read = post_per_read;
         tv.err = err.as<int32_t>(); tv.cnt = cnt.as<DevCounters>();
+        tv.job_cnt = job_cnt.as<int32_t>(); tv.jobs = jobs.p; tv.job_cap = job_cap;
         { const char* e = getenv("BWAMEM_HIP_DEBUGK"); tv.debug = e ? atoi(e) : 0; }
         return tv;
     }
@@ -497,16 +506,19 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
     const uint32_t r0 = spec.r0;
     const int T = (int)(spec.r1 - spec.r0), L = spec.L;
     int intv_cap = std::max(64, L + 8) * intv_cap_scale;
-    int attempts = 0;
+    int attempts = 0, job_cap_hint = 0;
+    size_t zpool_hint = (size_t)64 << 20;
     for (;;) {
         if (++attempts > 8) { fprintf(stderr, "[bwamem_hip] tile could not be sized after 8 attempts\n"); return false; }
         if (!ws.ensure_reads(T, L, intv_cap, out_cap, post_bytes_per_read(L, opt))) return false;
         if (!ws.ensure_seeds(std::max<int64_t>(ws.seed_cap, (int64_t)T * 16))) return false;
+        if (!ws.ensure_jobs(std::max(job_cap_hint, std::max(1024, T / 4)), 4 * L + 16, zpool_hint)) return false;
         TileView tv = ws.view();
         tv.n_reads = T; tv.max_len = L; tv.read_id0 = read_id0 + r0;
         tv.seq = b->d_seq.as<uint8_t>(); tv.seq_off = b->d_off.as<int64_t>() + r0;
         HIP_OK(hipMemsetAsync(ws.err.p, 0, 64, ws.stream));
         HIP_OK(hipMemsetAsync(ws.cnt.p, 0, sizeof(DevCounters), ws.stream));
+        HIP_OK(hipMemsetAsync(ws.job_cnt.p, 0, 64, ws.stream));
         TIMED(ws, K_SEED, launch_seed(ws.stream, ix->d, opt, tv));
         TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_seeds, tv.seed_off, T));
         int64_t n_occ = 0; int32_t err = 0; int32_t errv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -526,7 +538,14 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
         TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
         if (getenv("BWAMEM_HIP_DUMP") && T <= 64) debug_dump(ws, tv, T);
         TIMED(ws, K_POST, launch_post1(ws.stream, ix->d, opt, tv));
-        TIMED(ws, K_FINAL, launch_final_se(ws.stream, ix->d, opt, tv));
+        TIMED(ws, K_FINAL, launch_final_prep(ws.stream, ix->d, opt, tv));
+        int32_t n_jobs = 0;
+        HIP_OK(hipMemcpyAsync(&n_jobs, tv.job_cnt, 4, hipMemcpyDeviceToHost, ws.stream));
+        HIP_OK(hipStreamSynchronize(ws.stream));
+        if (n_jobs > ws.job_cap) { job_cap_hint = n_jobs + n_jobs / 4; { std::lock_guard<std::mutex> lk(g_stats.mu); ++g_stats.s.n_retries; } continue; }
+        TIMED(ws, K_FINAL, launch_gcigar(ws.stream, ix->d, opt, tv, n_jobs, ws.jobs.p, ws.job_out.p, ws.job_cig.as<uint32_t>(), ws.job_cig_cap,
+                                         ws.zpool.as<uint8_t>(), (unsigned long long)ws.zpool_cap, (unsigned long long*)(ws.job_cnt.as<int32_t>() + 2)));
+        TIMED(ws, K_FINAL, launch_final_se(ws.stream, ix->d, opt, tv, ws.job_out.p, ws.job_cig.as<uint32_t>(), ws.job_cig_cap));
         TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.out_len, tv.out_off, T));
         int64_t out_total = 0;
         DevCounters hc;
@@ -540,8 +559,10 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
             if (err & ERR_BAD_REG) { fprintf(stderr, "[bwamem_hip] internal error: extension produced an invalid region (tile read %d of call read %lld: n=%d qb=%d qe=%d rb=%d re=%d score=%d)\n", errv[1], (long long)(read_id0 + r0 + errv[1]), errv[2], errv[3], errv[4], errv[5], errv[6], errv[7]); return false; }
             if (err & ERR_LONG_READ) { fprintf(stderr, "[bwamem_hip] reads long enough to need seed re-scoring (mem_flt_chained_seeds) are not supported on the device path yet\n"); return false; }
             if (err & ERR_BTREE) { fprintf(stderr, "[bwamem_hip] internal error: chain B-tree pool exhausted\n"); return false; }
-            if (err & (ERR_SCRATCH | ERR_CIGAR_CAP)) { fprintf(stderr, "[bwamem_hip] internal error: post-processing scratch exhausted (err=%d)\n", err); return false; }
+            if ((err & (ERR_SCRATCH | ERR_CIGAR_CAP)) && !(err & (ERR_ZPOOL | ERR_JOB_CAP))) { fprintf(stderr, "[bwamem_hip] internal error: post-processing scratch exhausted (err=%d)\n", err); return false; }
             if (err & ERR_OUT_CAP) { out_cap *= 4; continue; }
+            if (err & ERR_ZPOOL) { zpool_hint = std::max(zpool_hint * 4, ws.zpool_cap * 4); continue; }
+            if (err & ERR_JOB_CAP) { job_cap_hint = std::max(ws.job_cap * 2, 4096); continue; }
             fprintf(stderr, "[bwamem_hip] device error flags %d\n", err); return false;
         }
         to.bytes = (size_t)out_total; to.d = nullptr;

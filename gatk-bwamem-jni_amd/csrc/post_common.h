@@ -145,6 +145,38 @@ DEV int global_dp(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const S
     return score;
 }
 
+// NM and MD of the CIGAR in S.cig[1..1+n_cig) (the tail of upstream bwa_gen_cigar2): MD lands NUL-terminated in S.md
+DEV void cigar_nm_md(const DevIndex& ix, PostScratch& S, const SeqAcc& A, int n_cig, bool fwd_strand, int* NM, int* l_md)
+{
+    const uint32_t* cigar = S.cig + 1;
+    int k, x, y, u, n_mm = 0, n_gap = 0;
+    const char* int2base = fwd_strand ? "ACGTN" : "TGCAN";
+    MdBuf md; md.s = S.md; md.cap = S.md_cap; md.l = 0; md.ovf = false;
+    for (k = 0, x = y = u = 0; k < n_cig; ++k) {
+        int op = cigar[k] & 0xf, len = (int)(cigar[k] >> 4);
+        if (op == 0) {
+            for (int i = 0; i < len; ++i) {
+                int tb = acc_t(ix, A, y + i);
+                if (acc_q(A, x + i) != tb) { md.putw(u); md.putc(int2base[tb]); ++n_mm; u = 0; }
+                else ++u;
+            }
+            x += len; y += len;
+        } else if (op == 2) {
+            if (k > 0 && k < n_cig - 1) {            // not for a leading / trailing D
+                md.putw(u); md.putc('^');
+                for (int i = 0; i < len; ++i) md.putc(int2base[acc_t(ix, A, y + i)]);
+                u = 0; n_gap += len;
+            }
+            y += len;
+        } else if (op == 1) { x += len; n_gap += len; }
+    }
+    md.putw(u);
+    md.s[md.l] = 0;
+    if (md.ovf) S.err |= ERR_CIGAR_CAP;
+    *NM = n_mm + n_gap;
+    if (l_md) *l_md = md.l;
+}
+
 // bwa_gen_cigar2: returns false when upstream would return a NULL cigar.  CIGAR lands in
 // S.cig[1..1+n), MD in S.md (NUL-terminated, length *l_md) when want_cigar.
 DEV bool gen_cigar2(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int w_, int l_query, const uint8_t* query,
@@ -180,35 +212,7 @@ DEV bool gen_cigar2(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int w
     }
     if (want_cigar) {
         if (n_cigar) *n_cigar = n_cig;
-        if (NM) {                                        // NM and MD
-            const uint32_t* cigar = S.cig + 1;
-            int k, x, y, u, n_mm = 0, n_gap = 0;
-            const char* int2base = rb < l_pac ? "ACGTN" : "TGCAN";
-            MdBuf md; md.s = S.md; md.cap = S.md_cap; md.l = 0; md.ovf = false;
-            for (k = 0, x = y = u = 0; k < n_cig; ++k) {
-                int op = cigar[k] & 0xf, len = (int)(cigar[k] >> 4);
-                if (op == 0) {
-                    for (int i = 0; i < len; ++i) {
-                        int tb = acc_t(ix, A, y + i);
-                        if (acc_q(A, x + i) != tb) { md.putw(u); md.putc(int2base[tb]); ++n_mm; u = 0; }
-                        else ++u;
-                    }
-                    x += len; y += len;
-                } else if (op == 2) {
-                    if (k > 0 && k < n_cig - 1) {
-                        md.putw(u); md.putc('^');
-                        for (int i = 0; i < len; ++i) md.putc(int2base[acc_t(ix, A, y + i)]);
-                        u = 0; n_gap += len;
-                    }
-                    y += len;
-                } else if (op == 1) { x += len; n_gap += len; }
-            }
-            md.putw(u);
-            md.s[md.l] = 0;
-            if (md.ovf) S.err |= ERR_CIGAR_CAP;
-            *NM = n_mm + n_gap;
-            if (l_md) *l_md = md.l;
-        }
+        if (NM) cigar_nm_md(ix, S, A, n_cig, rb < l_pac, NM, l_md);
     }
     return true;
 }
@@ -240,6 +244,11 @@ DEV int approx_mapq_se(const DevIndex& ix, const MemOpt& opt, PostScratch& S, co
     return mapq;
 }
 
+// CIGARs computed ahead by the wave-parallel global-alignment kernel (k_cigar.hip) for the regions that need DP
+struct DpJob { int32_t read, reg; };
+struct DpOut { int32_t score, n_cigar; };
+struct JobView { const DpOut* out; const uint32_t* cig; int cig_cap; };
+
 DEV int infer_bw(int l1, int l2, int score, int a, int q, int r)
 {
     int w, d;
@@ -250,8 +259,24 @@ DEV int infer_bw(int l1, int l2, int score, int a, int q, int r)
     return w;
 }
 
-// mem_reg2aln; ar == 0 gives the unmapped record
-DEV AlnRec reg2aln(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int l_query, const uint8_t* query, const AlnReg* ar)
+// first band of mem_reg2aln's retry loop
+DEV int first_w2(const MemOpt& opt, const AlnReg& ar)
+{
+    int tmp = infer_bw(ar.qe - ar.qb, (int)(ar.re - ar.rb), ar.truesc, opt.a, opt.o_del, opt.e_del);
+    int w2  = infer_bw(ar.qe - ar.qb, (int)(ar.re - ar.rb), ar.truesc, opt.a, opt.o_ins, opt.e_ins);
+    w2 = w2 > tmp ? w2 : tmp;
+    if (w2 > opt.w) w2 = w2 < ar.w ? w2 : ar.w;
+    return w2 < opt.w << 2 ? w2 : opt.w << 2;
+}
+// does mem_reg2aln run a banded global alignment for this region (false: the ungapped shortcut of bwa_gen_cigar2)?
+DEV bool region_needs_dp(const MemOpt& opt, const AlnReg& ar)
+{
+    if (ar.rb < 0 || ar.re < 0) return false;
+    return !(ar.qe - ar.qb == ar.re - ar.rb && first_w2(opt, ar) == 0);
+}
+
+// mem_reg2aln; ar == 0 gives the unmapped record.  jv != 0: regions flagged in pad_ take their CIGAR from the job pool.
+DEV AlnRec reg2aln(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int l_query, const uint8_t* query, const AlnReg* ar, const JobView* jv = 0)
 {
     AlnRec a;
     a.pos = 0; a.rid = 0; a.flag = 0; a.is_rev = 0; a.is_alt = 0; a.mapq = 0; a.NM = 0; a.n_cigar = 0;
@@ -267,14 +292,24 @@ DEV AlnRec reg2aln(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int l_
     w2  = infer_bw(qe - qb, (int)(re - rb), ar->truesc, opt.a, opt.o_ins, opt.e_ins);
     w2 = w2 > tmp ? w2 : tmp;
     if (w2 > opt.w) w2 = w2 < ar->w ? w2 : ar->w;
-    i = 0;
-    do {
-        w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
-        gen_cigar2(ix, opt, S, w2, qe - qb, query + qb, rb, re, &score, true, &n_cigar, &NM, &l_md);
-        if (score == last_sc || w2 == opt.w << 2) break;
-        last_sc = score;
-        w2 <<= 1;
-    } while (++i < 3 && score < ar->truesc - opt.a);
+    if (jv && ar->pad_ > 0) {                               // CIGAR was produced by k_gcigar (same retry loop, wave-parallel)
+        const int job = ar->pad_ - 1;
+        n_cigar = jv->out[job].n_cigar;
+        if (n_cigar + 2 > S.cig_cap) { S.err |= ERR_CIGAR_CAP; n_cigar = 0; }
+        const uint32_t* src = jv->cig + (size_t)job * jv->cig_cap;
+        for (i = 0; i < n_cigar; ++i) S.cig[1 + i] = src[i];
+        SeqAcc A; A.q = query + qb; A.qlen = qe - qb; A.rev = rb >= ix.l_pac; A.t0 = rb; A.tlen = (int)(re - rb);
+        cigar_nm_md(ix, S, A, n_cigar, rb < ix.l_pac, &NM, &l_md);
+    } else {
+        i = 0;
+        do {
+            w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+            gen_cigar2(ix, opt, S, w2, qe - qb, query + qb, rb, re, &score, true, &n_cigar, &NM, &l_md);
+            if (score == last_sc || w2 == opt.w << 2) break;
+            last_sc = score;
+            w2 <<= 1;
+        } while (++i < 3 && score < ar->truesc - opt.a);
+    }
     a.NM = NM & 0x3fffff;                                   // NM:22 bit-field upstream
     int64_t pos = bns_depos(ix, rb < ix.l_pac ? rb : re - 1, is_rev);
     a.is_rev = is_rev;
@@ -486,14 +521,14 @@ DEV int xa_prepare(const MemOpt& opt, int n, const AlnReg* a, int32_t* cnt, int3
 
 // append the XA string of primary k to ob; returns its length
 DEV int xa_emit(const DevIndex& ix, const MemOpt& opt, PostScratch& S, OutBuf& ob, int l_query, const uint8_t* query,
-                int n, const AlnReg* a, const int32_t* cnt, const int32_t* has_alt, int k)
+                int n, const AlnReg* a, const int32_t* cnt, const int32_t* has_alt, int k, const JobView* jv = 0)
 {
     int start = ob.len;
     if (cnt[k] == 0) return 0;
     if (cnt[k] > opt.max_XA_hits_alt || (!has_alt[k] && cnt[k] > opt.max_XA_hits)) return 0;
     for (int i = 0; i < n; ++i) {
         if (get_pri_idx(opt.XA_drop_ratio, a, i) != k) continue;
-        AlnRec t = reg2aln(ix, opt, S, l_query, query, &a[i]);
+        AlnRec t = reg2aln(ix, opt, S, l_query, query, &a[i], jv);
         const char* nm = ix.names + ix.ann_name_off[t.rid];
         int nl = ix.ann_name_off[t.rid + 1] - ix.ann_name_off[t.rid] - 1;
         for (int j = 0; j < nl; ++j) ob.putc(nm[j]);
@@ -510,7 +545,7 @@ DEV int xa_emit(const DevIndex& ix, const MemOpt& opt, PostScratch& S, OutBuf& o
 // upstream mem_aln2sam's flag prologue followed by the reference's fmt_BAMish (jnibwa.c:43-97).
 // xa_* describe how to produce the XA string of this record (k < 0: none).
 DEV void aln2out(const DevIndex& ix, const MemOpt& opt, PostScratch& S, OutBuf& ob, int n_recs, int which, AlnRec p, const MateInfo* m_,
-                 int l_query, const uint8_t* query, int n_regs, const AlnReg* regs, const int32_t* cnt, const int32_t* has_alt, int xa_k)
+                 int l_query, const uint8_t* query, int n_regs, const AlnReg* regs, const int32_t* cnt, const int32_t* has_alt, int xa_k, const JobView* jv = 0)
 {
     MateInfo mt; const bool has_m = m_ != 0;
     if (has_m) mt = *m_;
@@ -545,7 +580,7 @@ DEV void aln2out(const DevIndex& ix, const MemOpt& opt, PostScratch& S, OutBuf& 
         int at = ob.len;
         ob.put32(0);                                    // nXA, patched below
         if (xa_k >= 0 && cnt) {
-            int nXA = xa_emit(ix, opt, S, ob, l_query, query, n_regs, regs, cnt, has_alt, xa_k);
+            int nXA = xa_emit(ix, opt, S, ob, l_query, query, n_regs, regs, cnt, has_alt, xa_k, jv);
             ob.pad4();
             if (!ob.ovf) *(int32_t*)(ob.p + at) = nXA;
         }
@@ -565,7 +600,7 @@ DEV void aln2out(const DevIndex& ix, const MemOpt& opt, PostScratch& S, OutBuf& 
 
 // mem_reg2sam: select the records of one read and write them
 DEV void reg2sam(const DevIndex& ix, const MemOpt& opt, PostScratch& S, OutBuf& ob, int l_query, const uint8_t* query,
-                 int n, AlnReg* a, int32_t* zbuf, int extra_flag, const MateInfo* m)
+                 int n, AlnReg* a, int32_t* zbuf, int extra_flag, const MateInfo* m, const JobView* jv = 0)
 {
     int32_t *cnt = 0, *has_alt = 0;
     if (!(opt.flag & MEM_F_ALL) && n > 0) {
@@ -592,14 +627,14 @@ DEV void reg2sam(const DevIndex& ix, const MemOpt& opt, PostScratch& S, OutBuf& 
         if (p->score < opt.T) continue;
         if (p->secondary >= 0 && (p->is_alt || !(opt.flag & MEM_F_ALL))) continue;
         if (p->secondary >= 0 && p->secondary < INT_MAX_ && (float)p->score < (float)a[p->secondary].score * opt.drop_ratio) continue;
-        AlnRec q = reg2aln(ix, opt, S, l_query, query, p);
+        AlnRec q = reg2aln(ix, opt, S, l_query, query, p, jv);
         q.flag |= extra_flag;
         if (p->secondary >= 0) q.sub = -1;
         if (l && p->secondary < 0) q.flag |= (opt.flag & MEM_F_NO_MULTI) ? 0x10000 : 0x800;
         if (l && !p->is_alt && q.mapq > mapq0) q.mapq = mapq0;
         if (l == 0) mapq0 = q.mapq;
         // the record's own CIGAR/MD must be written before XA reuses the scratch: aln2out does that in order
-        aln2out(ix, opt, S, ob, n_aa, l, q, m, l_query, query, n, a, cnt, has_alt, cnt ? k : -1);
+        aln2out(ix, opt, S, ob, n_aa, l, q, m, l_query, query, n, a, cnt, has_alt, cnt ? k : -1, jv);
         ++l;
     }
 }
