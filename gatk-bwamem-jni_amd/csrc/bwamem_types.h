@@ -8,6 +8,7 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+#include <hip/hip_runtime.h>
 
 struct MemOpt {
     int a, b;
@@ -51,11 +52,15 @@ enum {
 };
 
 // ---- FM-index + reference resident in HBM ----
-// occ/bwt blocks: one 64-byte line per 128 BWT symbols = 4 x u64 cumulative counts + 8 x u32 of
-// 16 symbols each, MSB first.  The block array is 64-byte aligned in HBM so
-// one rank query touches exactly one line.
+// The image's occ/bwt array (one 64-byte line per 128 symbols with 4 x u64 counts) is
+// re-blocked once at openIndex into 32-byte blocks of 64 symbols: 4 x u32 counts relative to a superblock
+// (2^20 symbols) + 4 x u32 of 16 symbols each, MSB first.  A rank query then needs two 16-byte lane loads
+// instead of four and popcounts at most 4 words instead of 8; the superblock table (a few hundred KB) stays
+// in cache.  The seeding kernel is bound by per-lane vector-memory requests, so this halves its cost.
+#define OCC_SUPER_SHIFT 20
 struct DevIndex {
-    const uint32_t* bwt;
+    const uint4* occ;          // 2 x uint4 per 64-symbol block: {cnt[4]}, {sym[4]}
+    const uint64_t* occ_super; // [n_super][4] absolute counts at superblock starts
     const uint64_t* sa;        // sampled every sa_intv ranks; sa[0] = (u64)-1
     const uint8_t*  pac;       // 2 bit/base, first base in the two MSBs
     const int64_t*  ann_offset;
@@ -114,7 +119,7 @@ struct TileView {
     int32_t intv_cap;             // per-read capacity of intv / scratch vectors
     Intv* intv;                   // [n_reads][intv_cap]
     int32_t* n_intv;              // [n_reads]
-    Intv* smem_scratch;           // [n_reads/64][2][smem_cap][64 lanes]  (prev, curr), lane-interleaved
+    Intv* smem_scratch;           // [n_reads/64][2][smem_cap][64 lanes] x 16-byte packed candidates (prev, curr), lane-interleaved
     int32_t smem_cap;
     int32_t* l_rep;               // [n_reads]
     int32_t* n_seeds;             // [n_reads] -> exclusive scan in seed_off

@@ -1,5 +1,5 @@
 // dev_common.h -- device-side building blocks shared by the kernels: FM-index rank
-// queries on the 64-byte occ/bwt blocks, bidirectional interval extension, sampled-SA
+// queries on the 32-byte occ blocks, bidirectional interval extension, sampled-SA
 // lookup, packed-reference access, contig lookup, and the order-exact introsort.
 //
 // Behavioural contract: upstream lh3/bwa bwt.c / bntseq.c / ksort.h as reached from the
@@ -26,67 +26,37 @@ DEV void occ4(const DevIndex& ix, uint64_t k, uint64_t cnt[4])
 {
     if (k == (uint64_t)-1) { cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; return; }
     k -= (k >= ix.primary);
-    const uint4* p = (const uint4*)(ix.bwt + (k >> 7 << 4));   // one 64-byte line
-    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-    int n = (int)(k & 127) + 1;                                // symbols of this block to count
+    const uint64_t b = k >> 6;
+    const uint4* p = ix.occ + 2 * b;                           // one 32-byte block
+    const uint4 c = p[0], s = p[1];
+    const uint64_t* sp = ix.occ_super + 4 * (b >> (OCC_SUPER_SHIFT - 6));
+    const int n = (int)(k & 63) + 1;                           // symbols of this block to count
     uint32_t c1 = 0, c2 = 0, c3 = 0;
-    cnt_word(q2.x, n, c1, c2, c3);       cnt_word(q2.y, n - 16, c1, c2, c3);
-    cnt_word(q2.z, n - 32, c1, c2, c3);  cnt_word(q2.w, n - 48, c1, c2, c3);
-    cnt_word(q3.x, n - 64, c1, c2, c3);  cnt_word(q3.y, n - 80, c1, c2, c3);
-    cnt_word(q3.z, n - 96, c1, c2, c3);  cnt_word(q3.w, n - 112, c1, c2, c3);
-    cnt[0] = ((uint64_t)q0.y << 32 | q0.x) + (uint32_t)(n - (int)(c1 + c2 + c3));
-    cnt[1] = ((uint64_t)q0.w << 32 | q0.z) + c1;
-    cnt[2] = ((uint64_t)q1.y << 32 | q1.x) + c2;
-    cnt[3] = ((uint64_t)q1.w << 32 | q1.z) + c3;
+    cnt_word(s.x, n, c1, c2, c3);       cnt_word(s.y, n - 16, c1, c2, c3);
+    cnt_word(s.z, n - 32, c1, c2, c3);  cnt_word(s.w, n - 48, c1, c2, c3);
+    cnt[0] = sp[0] + c.x + (uint32_t)(n - (int)(c1 + c2 + c3));
+    cnt[1] = sp[1] + c.y + c1;
+    cnt[2] = sp[2] + c.z + c2;
+    cnt[3] = sp[3] + c.w + c3;
 }
 
-// backward extension of the bi-interval (x0 = interval of P, x1 = interval of revcomp(P)) by
-// every base b: ok[b] is the interval of bP.  Row a3.
-DEV void extend_backward(const DevIndex& ix, const Intv& ik, Intv ok[4])
-{
-    uint64_t tk[4], tl[4];
-    occ4(ix, ik.x0 - 1, tk);
-    occ4(ix, ik.x0 - 1 + ik.size, tl);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ok[i].x0 = ix.L2[i] + 1 + tk[i];
-        ok[i].size = tl[i] - tk[i];
-    }
-    ok[3].x1 = ik.x1 + (ik.x0 <= ix.primary && ik.x0 + ik.size - 1 >= ix.primary);
-    ok[2].x1 = ok[3].x1 + ok[3].size;
-    ok[1].x1 = ok[2].x1 + ok[2].size;
-    ok[0].x1 = ok[1].x1 + ok[1].size;
-}
-
-// forward extension by base b == backward extension of the swapped interval by 3-b;
-// ok[c] (c = 3 - b) is the interval of Pb, as upstream's bwt_extend(..., is_back = 0) returns it.
-DEV void extend_forward(const DevIndex& ix, const Intv& ik, Intv ok[4])
-{
-    Intv sw; sw.x0 = ik.x1; sw.x1 = ik.x0; sw.size = ik.size; sw.info = ik.info;
-    extend_backward(ix, sw, ok);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { uint64_t t = ok[i].x0; ok[i].x0 = ok[i].x1; ok[i].x1 = t; }
-}
-
-// occ(k,.) and occ(l,.) for k <= l.  When both ranks fall into the same 128-symbol block (the common case once an
-// interval is small) the 64-byte line is fetched once -- upstream's bwt_2occ4 makes the same distinction.
+// occ(k,.) and occ(l,.) for k <= l.  When both ranks fall into the same 64-symbol block (the common case once an
+// interval is small) the block is fetched once -- upstream's bwt_2occ4 makes the same distinction.
 DEV void occ4_pair(const DevIndex& ix, uint64_t k, uint64_t l, uint64_t tk[4], uint64_t tl[4])
 {
     const uint64_t kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
-    if (k == (uint64_t)-1 || l == (uint64_t)-1 || (kk >> 7) != (ll >> 7)) { occ4(ix, k, tk); occ4(ix, l, tl); return; }
-    const uint4* p = (const uint4*)(ix.bwt + (kk >> 7 << 4));
-    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-    const int nk = (int)(kk & 127) + 1, nl = (int)(ll & 127) + 1;
+    if (k == (uint64_t)-1 || l == (uint64_t)-1 || (kk >> 6) != (ll >> 6)) { occ4(ix, k, tk); occ4(ix, l, tl); return; }
+    const uint64_t b = kk >> 6;
+    const uint4* p = ix.occ + 2 * b;
+    const uint4 c = p[0], s = p[1];
+    const uint64_t* sp = ix.occ_super + 4 * (b >> (OCC_SUPER_SHIFT - 6));
+    const int nk = (int)(kk & 63) + 1, nl = (int)(ll & 63) + 1;
     uint32_t a1 = 0, a2 = 0, a3 = 0, b1 = 0, b2 = 0, b3 = 0;
-    cnt_word(q2.x, nk, a1, a2, a3);       cnt_word(q2.x, nl, b1, b2, b3);
-    cnt_word(q2.y, nk - 16, a1, a2, a3);  cnt_word(q2.y, nl - 16, b1, b2, b3);
-    cnt_word(q2.z, nk - 32, a1, a2, a3);  cnt_word(q2.z, nl - 32, b1, b2, b3);
-    cnt_word(q2.w, nk - 48, a1, a2, a3);  cnt_word(q2.w, nl - 48, b1, b2, b3);
-    cnt_word(q3.x, nk - 64, a1, a2, a3);  cnt_word(q3.x, nl - 64, b1, b2, b3);
-    cnt_word(q3.y, nk - 80, a1, a2, a3);  cnt_word(q3.y, nl - 80, b1, b2, b3);
-    cnt_word(q3.z, nk - 96, a1, a2, a3);  cnt_word(q3.z, nl - 96, b1, b2, b3);
-    cnt_word(q3.w, nk - 112, a1, a2, a3); cnt_word(q3.w, nl - 112, b1, b2, b3);
-    const uint64_t c0 = (uint64_t)q0.y << 32 | q0.x, c1 = (uint64_t)q0.w << 32 | q0.z, c2 = (uint64_t)q1.y << 32 | q1.x, c3 = (uint64_t)q1.w << 32 | q1.z;
+    cnt_word(s.x, nk, a1, a2, a3);       cnt_word(s.x, nl, b1, b2, b3);
+    cnt_word(s.y, nk - 16, a1, a2, a3);  cnt_word(s.y, nl - 16, b1, b2, b3);
+    cnt_word(s.z, nk - 32, a1, a2, a3);  cnt_word(s.z, nl - 32, b1, b2, b3);
+    cnt_word(s.w, nk - 48, a1, a2, a3);  cnt_word(s.w, nl - 48, b1, b2, b3);
+    const uint64_t c0 = sp[0] + c.x, c1 = sp[1] + c.y, c2 = sp[2] + c.z, c3 = sp[3] + c.w;
     tk[0] = c0 + (uint32_t)(nk - (int)(a1 + a2 + a3)); tk[1] = c1 + a1; tk[2] = c2 + a2; tk[3] = c3 + a3;
     tl[0] = c0 + (uint32_t)(nl - (int)(b1 + b2 + b3)); tl[1] = c1 + b1; tl[2] = c2 + b2; tl[3] = c3 + b3;
 }
@@ -129,21 +99,18 @@ DEV uint64_t sa_lookup(const DevIndex& ix, uint64_t k, uint32_t& n_lf)
     while (k & mask) {
         ++sa; ++n_lf;
         if (k == ix.primary) { k = 0; continue; }
-        uint64_t x = k - (k > ix.primary);
-        const uint4* p = (const uint4*)(ix.bwt + (x >> 7 << 4));
-        uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-        uint32_t w[8] = { q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
-        int off = (int)(x & 127);
-        int c = 0;
+        const uint64_t x = k - (k > ix.primary), b = x >> 6;
+        const uint4* p = ix.occ + 2 * b;
+        const uint4 cv = p[0], s = p[1];
+        const uint64_t* sp = ix.occ_super + 4 * (b >> (OCC_SUPER_SHIFT - 6));
+        const int off = (int)(x & 63);
+        const uint32_t w = (off >> 4) == 0 ? s.x : (off >> 4) == 1 ? s.y : (off >> 4) == 2 ? s.z : s.w;
+        const int c = (int)(w >> ((~off & 15) << 1) & 3);       // BWT symbol at rank k
         uint32_t c1 = 0, c2 = 0, c3 = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if ((off >> 4) == i) c = (int)(w[i] >> ((~off & 15) << 1) & 3);
-            cnt_word(w[i], off + 1 - 16 * i, c1, c2, c3);
-        }
-        uint64_t base = c == 0 ? ((uint64_t)q0.y << 32 | q0.x) : c == 1 ? ((uint64_t)q0.w << 32 | q0.z)
-                      : c == 2 ? ((uint64_t)q1.y << 32 | q1.x) : ((uint64_t)q1.w << 32 | q1.z);
-        uint32_t add = c == 0 ? (uint32_t)(off + 1 - (int)(c1 + c2 + c3)) : c == 1 ? c1 : c == 2 ? c2 : c3;
+        cnt_word(s.x, off + 1, c1, c2, c3);  cnt_word(s.y, off - 15, c1, c2, c3);
+        cnt_word(s.z, off - 31, c1, c2, c3); cnt_word(s.w, off - 47, c1, c2, c3);
+        const uint64_t base = c == 0 ? sp[0] + cv.x : c == 1 ? sp[1] + cv.y : c == 2 ? sp[2] + cv.z : sp[3] + cv.w;
+        const uint32_t add = c == 0 ? (uint32_t)(off + 1 - (int)(c1 + c2 + c3)) : c == 1 ? c1 : c == 2 ? c2 : c3;
         k = ix.L2[c] + base + add;
     }
     return sa + ix.sa[k / (uint64_t)ix.sa_intv];

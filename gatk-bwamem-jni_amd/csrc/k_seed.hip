@@ -8,7 +8,6 @@
 // CU, not from parallelism inside a read.
 #include "dev_common.h"
 #include "kernels.h"
-#include "wave_ops.h"
 
 // Per-read interval vectors live in global scratch laid out [entry][lane]: when the 64 reads of a wave push or
 // read entry e together, the wave touches one contiguous 2 KB span instead of 64 scattered lines.
@@ -19,9 +18,116 @@ struct IntvVec {
     __device__ bool push(const Intv& v) { if (n >= cap) return false; a[(size_t)n * stride] = v; ++n; return true; }
 };
 
+// prev / curr candidates of one SMEM search: 16-byte packed entries (x0, x1, size: 37 bits each; end: 17 bits), so a
+// push or a read is one 16-byte lane request.  Limits (checked on the host): text < 2^37 symbols, reads < 2^17 bases.
+struct PackedVec {
+    uint4* a; int n; int cap; int stride;
+    static __device__ uint4 pack(const Intv& v) {
+        uint64_t lo = v.x0 | (v.x1 << 37), hi = (v.x1 >> 27) | (v.size << 10) | ((v.info & 0x1ffff) << 47);
+        uint4 r; r.x = (uint32_t)lo; r.y = (uint32_t)(lo >> 32); r.z = (uint32_t)hi; r.w = (uint32_t)(hi >> 32);
+        return r;
+    }
+    static __device__ Intv unpack(const uint4& r) {
+        uint64_t lo = (uint64_t)r.y << 32 | r.x, hi = (uint64_t)r.w << 32 | r.z;
+        Intv v; v.x0 = lo & 0x1fffffffffull; v.x1 = (lo >> 37) | ((hi & 0x3ff) << 27); v.size = (hi >> 10) & 0x1fffffffffull; v.info = hi >> 47;
+        return v;
+    }
+    __device__ Intv get(int i) const { return unpack(a[(size_t)i * stride]); }
+    __device__ uint4 raw(int i) const { return a[(size_t)i * stride]; }
+    __device__ void set_raw(int i, const uint4& v) { a[(size_t)i * stride] = v; }
+    __device__ bool push(const Intv& v) { if (n >= cap) return false; a[(size_t)n * stride] = pack(v); ++n; return true; }
+};
+
+DEV void pvec_reverse(PackedVec& v)
+{
+    for (int i = 0, j = v.n - 1; i < j; ++i, --j) { uint4 t = v.raw(i); v.set_raw(i, v.raw(j)); v.set_raw(j, t); }
+}
+
 DEV void vec_reverse(IntvVec& v, int from = 0)
 {
     for (int i = from, j = v.n - 1; i < j; ++i, --j) { Intv t = v.get(i); v.set(i, v.get(j)); v.set(j, t); }
+}
+
+// all SMEMs through position x with interval size >= min_intv, appended to mem when at least min_seed_len long
+// (the caller's filter, fused so no intermediate vector is needed); returns the next x.
+// Forward-extend recording each size change, then backward-extend every candidate in lock-step,
+// longest first (App. B "SMEM(x, min_intv)").
+DEV int smem1(const DevIndex& ix, int len, const uint8_t* q, int x, int min_intv, int min_seed_len,
+              IntvVec& mem, PackedVec& v0, PackedVec& v1, uint32_t& n_ext, bool& ovf)
+{
+    Intv ik, ok;
+    PackedVec *prev = &v0, *curr = &v1, *swap;
+    int i, j, c;
+    const int mem0 = mem.n;
+    uint64_t last_start = ~0ull;                 // start of the most recently emitted match (before the length filter)
+    bool any = false;
+    if (q[x] > 3) return x + 1;
+    if (min_intv < 1) min_intv = 1;
+    set_intv(ix, q[x], ik);
+    ik.info = (uint64_t)(x + 1);
+    for (i = x + 1, curr->n = 0; i < len; ++i) {
+        if (q[i] < 4) {
+            c = 3 - q[i];
+            ok = extend_one(ix, ik, c, 0); ++n_ext;
+            if (ok.size != ik.size) {
+                if (!curr->push(ik)) { ovf = true; return len; }
+                if (ok.size < (uint64_t)min_intv) break;
+            }
+            ik = ok; ik.info = (uint64_t)(i + 1);
+        } else {
+            if (!curr->push(ik)) { ovf = true; return len; }
+            break;
+        }
+    }
+    if (i == len) { if (!curr->push(ik)) { ovf = true; return len; } }
+    pvec_reverse(*curr);
+    int ret = (int)curr->get(0).info;
+    swap = curr; curr = prev; prev = swap;
+    for (i = x - 1; i >= -1; --i) {
+        c = i < 0 ? -1 : q[i] < 4 ? q[i] : -1;
+        for (j = 0, curr->n = 0; j < prev->n; ++j) {
+            Intv p = prev->get(j);
+            if (c >= 0) { ok = extend_one(ix, p, c, 1); ++n_ext; }
+            if (c < 0 || ok.size < (uint64_t)min_intv) {
+                if (curr->n == 0) {
+                    if (!any || (uint64_t)(i + 1) < last_start) {
+                        any = true; last_start = (uint64_t)(i + 1);
+                        ik = p; ik.info |= (uint64_t)(i + 1) << 32;
+                        if ((int)((uint32_t)ik.info - (uint32_t)(ik.info >> 32)) >= min_seed_len) { if (!mem.push(ik)) { ovf = true; return len; } }
+                    }
+                }
+            } else if (curr->n == 0 || ok.size != curr->get(curr->n - 1).size) {
+                ok.info = p.info;
+                if (!curr->push(ok)) { ovf = true; return len; }
+            }
+        }
+        if (curr->n == 0) break;
+        swap = curr; curr = prev; prev = swap;
+    }
+    vec_reverse(mem, mem0);                       // this call's matches in order of start
+    return ret;
+}
+
+// pass 3: greedy forward seed (row a5)
+DEV int seed_strategy1(const DevIndex& ix, int len, const uint8_t* q, int x, int min_len, int max_intv, Intv& mem, uint32_t& n_ext)
+{
+    Intv ik, ok;
+    mem.x0 = mem.x1 = mem.size = mem.info = 0;
+    if (q[x] > 3) return x + 1;
+    set_intv(ix, q[x], ik);
+    for (int i = x + 1; i < len; ++i) {
+        if (q[i] < 4) {
+            int c = 3 - q[i];
+            ok = extend_one(ix, ik, c, 0); ++n_ext;
+            if (ok.size < (uint64_t)(int64_t)max_intv && i - x >= min_len) {
+                mem = ok;
+                mem.info = (uint64_t)x << 32 | (uint32_t)(i + 1);
+                return i + 1;
+            }
+            ik = ok;
+        } else return i + 1;
+    }
+    return len;
 }
 
 // ASCII -> 0..4 in place (upstream nst_nt4_table; bytes < 4 are kept as they are)
@@ -39,197 +145,74 @@ __global__ void k_encode(uint8_t* seq, int64_t n_bytes)
     }
 }
 
-// mem_collect_intv (row a6): three seeding passes, written as a per-lane state machine.
-//
-// Upstream's control flow is four nested data-dependent loops per read.  Run naively one-read-per-lane, the
-// lanes of a wave sit in different loops most of the time and the wave executes each lane's interval
-// extensions almost serially (PMC: ~10 k extend steps per wave for ~860 per read).  Here every iteration of
-// ONE wave-level loop performs exactly one interval extension per lane -- the expensive part: two dependent
-// 64-byte occ gathers plus the popcounts -- and all bookkeeping between two extensions is cheap per-lane
-// state transitions.  The sequence of extensions and pushes of each read is exactly upstream's
-// (bwt_smem1 / bwt_seed_strategy1 / mem_collect_intv), so the resulting interval list is identical.
-enum { ST_NEXT = 0, ST_FWD = 1, ST_BWD = 2, ST_P3 = 3, ST_DONE = 4 };
-
+// mem_collect_intv (row a6) + the per-read bookkeeping mem_chain does before looking up the SA:
+// l_rep (repetitive fraction numerator) and the number of occurrences each interval contributes.
 __global__ void k_seed(DevIndex ix, MemOpt opt, TileView tv)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_range = r < tv.n_reads;
-    const int rr = in_range ? r : 0;
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_ext = 0;
-    const uint8_t* q = tv.seq + tv.seq_off[rr];
-    const int len = (int)(tv.seq_off[rr + 1] - tv.seq_off[rr] - 1);
-    // scratch of wave-group g = r/64: [2 vectors][smem_cap entries][64 lanes]
-    Intv* sc = tv.smem_scratch + ((size_t)(rr >> 6) * 2 * tv.smem_cap) * 64 + (rr & 63);
-    // prev / curr candidate vectors: two lane-interleaved arrays whose roles swap; kept as plain registers
-    // (an array indexed by the role bit would live in private scratch memory)
-    Intv* const pa = sc; Intv* const pb = sc + (size_t)tv.smem_cap * 64;
-    const int vcap = tv.smem_cap;
-    int na = 0, nb = 0;
-#define PREV_PTR (pv ? pb : pa)
-#define CURR_PTR (pv ? pa : pb)
-#define PREV_N (pv ? nb : na)
-#define CURR_N (pv ? na : nb)
-#define SET_CURR_N(v) do { if (pv) na = (v); else nb = (v); } while (0)
-#define CURR_PUSH(val) do { int n_ = CURR_N; if (n_ >= vcap) ovf = true; else { CURR_PTR[(size_t)n_ * 64] = (val); SET_CURR_N(n_ + 1); } } while (0)
-#define CURR_REVERSE() do { Intv* p_ = CURR_PTR; for (int a_ = 0, b_ = CURR_N - 1; a_ < b_; ++a_, --b_) { Intv t_ = p_[(size_t)a_ * 64]; p_[(size_t)a_ * 64] = p_[(size_t)b_ * 64]; p_[(size_t)b_ * 64] = t_; } } while (0)
-    IntvVec mem = { tv.intv + (size_t)rr * tv.intv_cap, 0, tv.intv_cap, 1 };
-    const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
-    const int min_seed_len = opt.min_seed_len;
-
-    int st = (in_range && len >= min_seed_len) ? ST_NEXT : ST_DONE;
-    int pass = 1, x = 0, i = 0, j = 0, c = 0, sx = 0, min_intv = 1, ret = 0, k2 = 0, old_n = 0, mem0 = 0;
-    int pv = 0;                         // role bit: pv = 0 -> pa is prev, pb is curr
-    bool any = false, ovf = false, row_start = false;
-    uint64_t last_start = 0, last_curr_size = 0;
-    Intv ik, req, ok;
-    ik.x0 = ik.x1 = ik.size = ik.info = 0; req = ik; ok = ik;
-
-    while (wave_any(st != ST_DONE)) {
-        bool need = false;
-        int is_back = 0;
-        // ---- (a) per-lane transitions until this lane needs an interval extension
-        while (st != ST_DONE && !need) {
-            if (ovf) { st = ST_DONE; break; }
-            if (st == ST_NEXT) {
-                int nx = -1, nmin = 1;
-                if (pass == 1) {
-                    while (x < len && q[x] > 3) ++x;
-                    if (x < len) { nx = x; nmin = 1; }
-                    else { pass = 2; old_n = mem.n; k2 = 0; }
-                } else if (pass == 2) {
-                    while (k2 < old_n) {
-                        Intv p = mem.get(k2);
-                        int s0 = (int)(p.info >> 32), e0 = (int)(int32_t)p.info;
-                        if (e0 - s0 < split_len || p.size > (uint64_t)(int64_t)opt.split_width) { ++k2; continue; }
-                        nx = (s0 + e0) >> 1; nmin = (int)(p.size + 1);
-                        break;
-                    }
-                    if (nx < 0) { pass = 3; x = 0; }
-                    else if (q[nx] > 3) { ++k2; nx = -1; }          // bwt_smem1 returns at once on an ambiguous base
-                } else {
-                    if (!(opt.max_mem_intv > 0)) { st = ST_DONE; }
-                    else {
-                        while (x < len && q[x] > 3) ++x;
-                        if (x >= len) st = ST_DONE;
-                        else { set_intv(ix, q[x], ik); sx = x; i = x + 1; st = ST_P3; }
-                    }
-                }
-                if (nx >= 0) {                                       // enter bwt_smem1(nx, nmin)
-                    sx = nx; min_intv = nmin < 1 ? 1 : nmin;
-                    set_intv(ix, q[sx], ik);
-                    ik.info = (uint64_t)(sx + 1);
-                    i = sx + 1; SET_CURR_N(0); mem0 = mem.n; any = false;
-                    st = ST_FWD;
-                }
-            } else if (st == ST_FWD) {
-                bool end_fwd = false;
-                if (i < len) {
-                    if (q[i] < 4) { req = ik; c = 3 - q[i]; is_back = 0; need = true; }
-                    else { CURR_PUSH(ik); end_fwd = true; }
-                } else { CURR_PUSH(ik); end_fwd = true; }
-                if (end_fwd && !ovf) {                               // longest match first, then walk backwards
-                    CURR_REVERSE();
-                    ret = (int)CURR_PTR[0].info;
-                    pv ^= 1;
-                    i = sx - 1; j = 0; row_start = true;
-                    st = ST_BWD;
-                }
-            } else if (st == ST_BWD) {
-                if (row_start) { c = i < 0 ? -1 : (q[i] < 4 ? q[i] : -1); SET_CURR_N(0); row_start = false; }
-                if (j < PREV_N) {
-                    req = PREV_PTR[(size_t)j * 64];
-                    if (c >= 0) { is_back = 1; need = true; }
-                    else {                                           // start of the read or an ambiguous base: every candidate ends here
-                        if (CURR_N == 0 && (!any || (uint64_t)(i + 1) < last_start)) {
-                            any = true; last_start = (uint64_t)(i + 1);
-                            Intv m = req; m.info |= (uint64_t)(i + 1) << 32;
-                            if ((int)((uint32_t)m.info - (uint32_t)(m.info >> 32)) >= min_seed_len) { if (!mem.push(m)) ovf = true; }
-                        }
-                        ++j;
-                    }
-                } else if (CURR_N == 0) {                            // no candidate survived: this bwt_smem1 call is complete
-                    vec_reverse(mem, mem0);
-                    if (pass == 1) x = ret; else ++k2;
-                    st = ST_NEXT;
-                } else { pv ^= 1; --i; j = 0; row_start = true; }
-            } else {                                                 // ST_P3: bwt_seed_strategy1
-                if (i < len) {
-                    if (q[i] < 4) { req = ik; c = 3 - q[i]; is_back = 0; need = true; }
-                    else { x = i + 1; st = ST_NEXT; }
-                } else { x = len; st = ST_NEXT; }
-            }
-        }
-        // ---- (b) one interval extension per lane, executed by the whole wave together
-        if (need) { ok = extend_one(ix, req, c, is_back); ++n_ext; }
-        // ---- (c) consume the result
-        if (need) {
-            if (st == ST_FWD) {
-                bool stop = false;
-                if (ok.size != ik.size) {
-                    CURR_PUSH(ik);
-                    if (ok.size < (uint64_t)min_intv) stop = true;
-                }
-                if (stop) {                                          // upstream breaks with i < len: no final push
-                    if (!ovf) {
-                        CURR_REVERSE();
-                        ret = (int)CURR_PTR[0].info;
-                        pv ^= 1;
-                        i = sx - 1; j = 0; row_start = true;
-                        st = ST_BWD;
-                    }
-                } else { ik = ok; ik.info = (uint64_t)(i + 1); ++i; }
-            } else if (st == ST_BWD) {
-                if (ok.size < (uint64_t)min_intv) {
-                    if (CURR_N == 0 && (!any || (uint64_t)(i + 1) < last_start)) {
-                        any = true; last_start = (uint64_t)(i + 1);
-                        Intv m = req; m.info |= (uint64_t)(i + 1) << 32;
-                        if ((int)((uint32_t)m.info - (uint32_t)(m.info >> 32)) >= min_seed_len) { if (!mem.push(m)) ovf = true; }
-                    }
-                } else if (CURR_N == 0 || ok.size != last_curr_size) {
-                    ok.info = req.info;
-                    CURR_PUSH(ok);
-                    last_curr_size = ok.size;
-                }
-                ++j;
-            } else {                                                 // ST_P3
-                if (ok.size < (uint64_t)(int64_t)(int)opt.max_mem_intv && i - sx >= min_seed_len) {
-                    Intv m = ok;
-                    m.info = (uint64_t)sx << 32 | (uint32_t)(i + 1);
-                    if (m.size > 0) { if (!mem.push(m)) ovf = true; }
-                    x = i + 1; st = ST_NEXT;
-                } else { ik = ok; ++i; }
-            }
-        }
-    }
-
-    if (in_range) {
+    if (r < tv.n_reads) {
+        const uint8_t* q = tv.seq + tv.seq_off[r];
+        int len = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
+        // scratch of wave-group g = r/64: [2 vectors][smem_cap entries][64 lanes]
+        uint4* sc = (uint4*)tv.smem_scratch + ((size_t)(r >> 6) * 2 * tv.smem_cap) * 64 + (r & 63);
+        PackedVec v0 = { sc, 0, tv.smem_cap, 64 };
+        PackedVec v1 = { sc + (size_t)tv.smem_cap * 64, 0, tv.smem_cap, 64 };
+        IntvVec mem = { tv.intv + (size_t)r * tv.intv_cap, 0, tv.intv_cap, 1 };
+        bool ovf = false;
         int n_seeds = 0, l_rep = 0;
-        if (!ovf) {
-            // sort by info.  Intervals with equal info are the same substring, hence identical records, so the
-            // order upstream's unstable sort leaves them in is unobservable: a plain insertion sort suffices.
-            for (int a = 1; a < mem.n; ++a) {
-                Intv t = mem.a[a];
-                int b = a;
-                while (b > 0 && mem.a[b - 1].info > t.info) { mem.a[b] = mem.a[b - 1]; --b; }
-                mem.a[b] = t;
+        if (len >= opt.min_seed_len) {
+            int x = 0;
+            int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
+            while (x < len && !ovf) {                       // pass 1: all SMEMs
+                if (q[x] < 4) x = smem1(ix, len, q, x, 1, opt.min_seed_len, mem, v0, v1, n_ext, ovf);
+                else ++x;
             }
-            int b = 0, e = 0;
-            int32_t* iso = tv.intv_seed_off + (size_t)r * tv.intv_cap;
-            for (int a = 0; a < mem.n; ++a) {
-                Intv p = mem.a[a];
-                int sb = (int)(p.info >> 32), se = (int)(uint32_t)p.info;
-                iso[a] = n_seeds;
-                {
-                    int64_t step = p.size > (uint64_t)(int64_t)opt.max_occ ? (int64_t)(p.size / (uint64_t)opt.max_occ) : 1;
-                    int64_t cc = ((int64_t)p.size + step - 1) / step;
-                    n_seeds += (int)(cc < opt.max_occ ? cc : opt.max_occ);
+            int old_n = mem.n;
+            for (int k = 0; k < old_n && !ovf; ++k) {       // pass 2: re-seed long, rare SMEMs
+                Intv p = mem.get(k);
+                int start = (int)(p.info >> 32), end = (int)(int32_t)p.info;
+                if (end - start < split_len || p.size > (uint64_t)(int64_t)opt.split_width) continue;
+                smem1(ix, len, q, (start + end) >> 1, (int)(p.size + 1), opt.min_seed_len, mem, v0, v1, n_ext, ovf);
+            }
+            if (opt.max_mem_intv > 0) {                     // pass 3: greedy forward seeds
+                x = 0;
+                while (x < len && !ovf) {
+                    if (q[x] < 4) {
+                        Intv m;
+                        x = seed_strategy1(ix, len, q, x, opt.min_seed_len, (int)opt.max_mem_intv, m, n_ext);
+                        if (m.size > 0) { if (!mem.push(m)) ovf = true; }
+                    } else ++x;
                 }
-                if (p.size <= (uint64_t)(int64_t)opt.max_occ) continue;
-                if (sb > e) { l_rep += e - b; b = sb; e = se; }
-                else e = e > se ? e : se;
             }
-            l_rep += e - b;
-        } else { atomicOr(tv.err, ERR_INTV_CAP); mem.n = 0; }
+            if (!ovf) {
+                // sort by info.  Intervals with equal info are the same substring, hence identical records, so the
+                // order upstream's unstable sort leaves them in is unobservable: a plain insertion sort suffices.
+                for (int i = 1; i < mem.n; ++i) {
+                    Intv t = mem.a[i];
+                    int j = i;
+                    while (j > 0 && mem.a[j - 1].info > t.info) { mem.a[j] = mem.a[j - 1]; --j; }
+                    mem.a[j] = t;
+                }
+                int b = 0, e = 0;
+                int32_t* iso = tv.intv_seed_off + (size_t)r * tv.intv_cap;
+                for (int i = 0; i < mem.n; ++i) {
+                    Intv p = mem.a[i];
+                    int sb = (int)(p.info >> 32), se = (int)(uint32_t)p.info;
+                    iso[i] = n_seeds;
+                    {
+                        int64_t step = p.size > (uint64_t)(int64_t)opt.max_occ ? (int64_t)(p.size / (uint64_t)opt.max_occ) : 1;
+                        int64_t c = ((int64_t)p.size + step - 1) / step;
+                        n_seeds += (int)(c < opt.max_occ ? c : opt.max_occ);
+                    }
+                    if (p.size <= (uint64_t)(int64_t)opt.max_occ) continue;
+                    if (sb > e) { l_rep += e - b; b = sb; e = se; }
+                    else e = e > se ? e : se;
+                }
+                l_rep += e - b;
+            }
+        }
+        if (ovf) { atomicOr(tv.err, ERR_INTV_CAP); mem.n = 0; n_seeds = 0; l_rep = 0; }
         tv.n_intv[r] = mem.n;
         tv.n_seeds[r] = n_seeds;
         tv.l_rep[r] = l_rep;
@@ -296,6 +279,36 @@ __global__ void k_sa(DevIndex ix, MemOpt opt, TileView tv, int64_t n_occ)
     unsigned long long a = n_lf, b = n_sa;
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
     if ((threadIdx.x & 63) == 0) { count_add(&tv.cnt->n_lf, a); count_add(&tv.cnt->n_sa, b); }
+}
+
+// image occ/bwt layout (128-symbol blocks: 4 x u64 counts + 8 x u32 symbols) -> device layout (see bwamem_types.h)
+__global__ void k_build_occ64(const uint32_t* bwt, uint64_t n_blocks, uint64_t n_super, uint4* occ, uint64_t* super)
+{
+    uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_super) {                                          // absolute counts at symbol b * 2^20
+        const uint64_t* src = (const uint64_t*)(bwt + ((b << OCC_SUPER_SHIFT) >> 7 << 4));
+        for (int c = 0; c < 4; ++c) super[4 * b + c] = src[c];
+    }
+    if (b >= n_blocks) return;
+    const uint32_t* blk = bwt + (b >> 1 << 4);                  // the 128-symbol source block
+    const uint64_t* cnt = (const uint64_t*)blk;
+    const uint32_t* sym = blk + 8 + ((b & 1) << 2);
+    const uint64_t* sp = (const uint64_t*)(bwt + (((b >> (OCC_SUPER_SHIFT - 6)) << OCC_SUPER_SHIFT) >> 7 << 4));
+    uint32_t c1 = 0, c2 = 0, c3 = 0;
+    if (b & 1) for (int i = 0; i < 4; ++i) cnt_word(blk[8 + i], 16, c1, c2, c3);   // first half of the source block
+    uint4 c, s;
+    c.x = (uint32_t)(cnt[0] - sp[0]) + ((b & 1) ? 64 - (c1 + c2 + c3) : 0);
+    c.y = (uint32_t)(cnt[1] - sp[1]) + c1;
+    c.z = (uint32_t)(cnt[2] - sp[2]) + c2;
+    c.w = (uint32_t)(cnt[3] - sp[3]) + c3;
+    s.x = sym[0]; s.y = sym[1]; s.z = sym[2]; s.w = sym[3];
+    occ[2 * b] = c; occ[2 * b + 1] = s;
+}
+
+void launch_build_occ64(hipStream_t st, const uint32_t* bwt, uint64_t n_blocks, uint64_t n_super, uint4* occ, uint64_t* super)
+{
+    uint64_t n = n_blocks > n_super ? n_blocks : n_super;
+    hipLaunchKernelGGL(k_build_occ64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bwt, n_blocks, n_super, occ, super);
 }
 
 void launch_encode(hipStream_t st, uint8_t* seq, int64_t n_bytes)

@@ -73,7 +73,7 @@ struct Workspace {
     bool ensure_reads(int T_, int L_, int intv_cap_, int out_cap_, int64_t post_per_read_) {
         T = T_; L = L_; intv_cap = intv_cap_; smem_cap = L_ + 2; out_cap = out_cap_; post_per_read = post_per_read_;
         size_t t = (size_t)T;
-        return intv.ensure(t * intv_cap * sizeof(Intv)) && n_intv.ensure(t * 4) && smem.ensure(((t + 63) / 64 * 64) * 2 * smem_cap * sizeof(Intv))
+        return intv.ensure(t * intv_cap * sizeof(Intv)) && n_intv.ensure(t * 4) && smem.ensure(((t + 63) / 64 * 64) * 2 * smem_cap * 16)
             && l_rep.ensure(t * 4) && n_seeds.ensure(t * 4) && seed_off.ensure((t + 1) * 8) && intv_seed_off.ensure(t * intv_cap * 4)
             && n_chains.ensure(t * 4) && n_regs.ensure(t * 4) && out.ensure(t * out_cap) && out_len.ensure(t * 4)
             && out_off.ensure((t + 1) * 8) && post.ensure(t * (size_t)post_per_read) && err.ensure(64) && cnt.ensure(sizeof(DevCounters));
@@ -119,7 +119,7 @@ struct bwaidx_s {
     HostIndex h;
     int device = 0;
     DevIndex d;
-    DevBuf d_bwt, d_sa, d_pac, d_ann_off, d_ann_len, d_ann_alt, d_name_off, d_names, d_log;
+    DevBuf d_occ, d_super, d_sa, d_pac, d_ann_off, d_ann_len, d_ann_alt, d_name_off, d_names, d_log;
     std::mutex mu;                  // one call at a time per index/device
     Workspace ws;
     std::vector<Workspace*> extra_ws;   // further tiles in flight (one stream + host thread each)
@@ -145,10 +145,18 @@ static bool upload_index(bwaidx_s* ix)
     HIP_OK(hipSetDevice(ix->device));
     const HostIndex& h = ix->h;
     const int n = (int)h.contigs.size();
-    size_t bwt_bytes = ((size_t)h.bwt_size * 4 + 127) & ~(size_t)63;   // whole 64-byte lines, plus slack for the last block
-    if (!ix->d_bwt.ensure(bwt_bytes) || !ix->d_sa.ensure((size_t)h.n_sa * 8) || !ix->d_pac.ensure((size_t)(h.l_pac / 4 + 1) + 16)) return false;
-    HIP_OK(hipMemset(ix->d_bwt.p, 0, ix->d_bwt.bytes));
-    HIP_OK(hipMemcpy(ix->d_bwt.p, h.bwt, (size_t)h.bwt_size * 4, hipMemcpyHostToDevice));
+    {   // upload the image's occ/bwt array to a scratch buffer and re-block it into the device layout
+        DevBuf tmp;
+        size_t bwt_bytes = ((size_t)h.bwt_size * 4 + 255) & ~(size_t)63;
+        const uint64_t n_blocks = (h.seq_len + 63) / 64 + 1, n_super = (h.seq_len >> OCC_SUPER_SHIFT) + 1;
+        if (!tmp.ensure(bwt_bytes) || !ix->d_occ.ensure((size_t)n_blocks * 32 + 64) || !ix->d_super.ensure((size_t)n_super * 32 + 64)) { tmp.release(); return false; }
+        HIP_OK(hipMemset(tmp.p, 0, tmp.bytes));
+        HIP_OK(hipMemcpy(tmp.p, h.bwt, (size_t)h.bwt_size * 4, hipMemcpyHostToDevice));
+        launch_build_occ64(0, tmp.as<uint32_t>(), n_blocks, n_super, ix->d_occ.as<uint4>(), ix->d_super.as<uint64_t>());
+        HIP_OK(hipDeviceSynchronize());
+        tmp.release();
+    }
+    if (!ix->d_sa.ensure((size_t)h.n_sa * 8) || !ix->d_pac.ensure((size_t)(h.l_pac / 4 + 1) + 16)) return false;
     HIP_OK(hipMemcpy(ix->d_sa.p, h.sa, (size_t)h.n_sa * 8, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(ix->d_pac.p, h.pac, (size_t)(h.l_pac / 4 + 1), hipMemcpyHostToDevice));
     std::vector<int64_t> off(n); std::vector<int32_t> len(n), alt(n), noff(n + 1);
@@ -173,7 +181,7 @@ static bool upload_index(bwaidx_s* ix)
     }
     DevIndex& d = ix->d;
     memset(&d, 0, sizeof d);
-    d.bwt = ix->d_bwt.as<uint32_t>(); d.sa = ix->d_sa.as<uint64_t>(); d.pac = ix->d_pac.as<uint8_t>();
+    d.occ = ix->d_occ.as<uint4>(); d.occ_super = ix->d_super.as<uint64_t>(); d.sa = ix->d_sa.as<uint64_t>(); d.pac = ix->d_pac.as<uint8_t>();
     d.ann_offset = ix->d_ann_off.as<int64_t>(); d.ann_len = ix->d_ann_len.as<int32_t>(); d.ann_is_alt = ix->d_ann_alt.as<int32_t>();
     d.ann_name_off = ix->d_name_off.as<int32_t>(); d.names = ix->d_names.as<char>(); d.log_tab = ix->d_log.as<double>();
     d.primary = h.primary; for (int i = 0; i < 5; ++i) d.L2[i] = h.L2[i];
@@ -184,7 +192,7 @@ static bool upload_index(bwaidx_s* ix)
 static void free_index(bwaidx_s* ix)
 {
     (void)hipSetDevice(ix->device);
-    DevBuf* all[] = { &ix->d_bwt, &ix->d_sa, &ix->d_pac, &ix->d_ann_off, &ix->d_ann_len, &ix->d_ann_alt, &ix->d_name_off, &ix->d_names, &ix->d_log };
+    DevBuf* all[] = { &ix->d_occ, &ix->d_super, &ix->d_sa, &ix->d_pac, &ix->d_ann_off, &ix->d_ann_len, &ix->d_ann_alt, &ix->d_name_off, &ix->d_names, &ix->d_log };
     for (DevBuf* b : all) b->release();
     ix->ws.release();
     for (Workspace* w : ix->extra_ws) { w->release(); delete w; }
@@ -343,7 +351,7 @@ static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes
             int len = (int)(b->h_off[r1 + 1] - b->h_off[r1] - 1);
             int L1 = std::max(L0, len);
             int icap = std::max(64, L1 + 8) * intv_cap_scale;
-            int64_t pr = (int64_t)icap * (sizeof(Intv) + 4) + 2 * (int64_t)(L1 + 2) * sizeof(Intv) + out_cap + post_bytes_per_read(L1, opt) + 64 * 300;
+            int64_t pr = (int64_t)icap * (sizeof(Intv) + 4) + 2 * (int64_t)(L1 + 2) * 16 + out_cap + post_bytes_per_read(L1, opt) + 64 * 300;
             if (r1 > r0 + 1 && pr * (int64_t)(r1 - r0 + 1) > budget && ((r1 - r0) & 1) == 0) break;
             L0 = L1; ++r1;
         }
@@ -488,7 +496,7 @@ static std::vector<TileSpec> plan_tiles(const bwamem_batch_s* b, const MemOpt& o
         while (r1 < b->n_reads && r1 - r0 < max_T) {
             int len = (int)(b->h_off[r1 + 1] - b->h_off[r1] - 1);
             int L1 = std::max(L0, len);
-            int64_t pr = (int64_t)std::max(64, L1 + 8) * (sizeof(Intv) + 4) + 2 * (int64_t)(L1 + 2) * sizeof(Intv) + 512 + post_bytes_per_read(L1, opt) + 64 * 300;
+            int64_t pr = (int64_t)std::max(64, L1 + 8) * (sizeof(Intv) + 4) + 2 * (int64_t)(L1 + 2) * 16 + 512 + post_bytes_per_read(L1, opt) + 64 * 300;
             if (r1 > r0 + (even ? 1u : 0u) && pr * (int64_t)(r1 - r0 + 1) > budget && (!even || ((r1 - r0) & 1) == 0)) break;
             L0 = L1; ++r1;
         }
@@ -598,6 +606,7 @@ static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, b
     HIP_OK(hipStreamSynchronize(ws.stream));
     timed_collect(ws);
     const std::vector<TileSpec> specs = plan_tiles(b, opt, false);
+    for (const TileSpec& t : specs) if (t.L >= (1 << 17) - 1) { fprintf(stderr, "[bwamem_hip] reads of 131071 bases or more are not supported\n"); return false; }
     b->tiles.assign(specs.size(), TileOut());
     const char* env_s = getenv("BWAMEM_HIP_STREAMS");
     int n_workers = std::max(1, std::min<int>((int)specs.size(), env_s ? atoi(env_s) : 3));
@@ -689,7 +698,7 @@ bwaidx_t* jnibwa_openIndex(int fd)
     if (mem == MAP_FAILED) return 0;
     bwaidx_s* ix = new bwaidx_s();
     ix->mem = (uint8_t*)mem; ix->l_mem = (size_t)st.st_size; ix->mmapped = true; ix->device = g_device;
-    if (!parse_index_image(ix->mem, ix->l_mem, ix->h) || !upload_index(ix)) {
+    if (!parse_index_image(ix->mem, ix->l_mem, ix->h) || ix->h.seq_len >= (1ull << 37) || !upload_index(ix)) {   // 37-bit ranks: packed SMEM candidates
         fprintf(stderr, "[bwamem_hip] cannot open index image (malformed image or no usable HIP device)\n");
         free_index(ix);
         munmap(mem, (size_t)st.st_size);
