@@ -163,6 +163,156 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
     return r;
 }
 
+// Register-resident form of the same DP for qlen + 1 <= 64 * C (every 150 bp read): lane l owns columns
+// t*64 + l, t < C; the H/E rows never leave the VGPRs, cross-lane traffic is DPP (prefix maximum, shift by one
+// lane), and the window bookkeeping is done on ballots.  No LDS, no barriers.  Same row-by-row decisions as
+// extend_wave() (the general, LDS-backed form used for longer queries), hence the same results.
+template <int C>
+static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, const uint8_t* query, int lane,
+                                         int qlen, int q0, int qstep, int tlen, int64_t t0, int tstep,
+                                         int w, int end_bonus, int zdrop, int h0, unsigned long long& n_cells)
+{
+    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    int i, beg, end, max, max_i, max_j, max_ins, max_del, max_ie, gscore, max_off;
+    int ehh[C], ehe[C], qc[C];
+    if (h0 < 0) h0 = 0;
+#pragma unroll
+    for (int t = 0; t < C; ++t) {                          // first row: decay from h0 by insertion costs
+        const int j = t * WAVE + lane;
+        int v = 0;
+        if (j == 0) v = h0;
+        else if (j <= qlen && h0 > oe_ins) {
+            int vj = h0 - oe_ins - (j - 1) * e_ins;
+            if (j == 1 || vj + e_ins > e_ins) v = vj;
+        }
+        ehh[t] = v; ehe[t] = 0;
+        qc[t] = j < qlen ? query[q0 + qstep * j] : 4;
+    }
+    {
+        int mx = 0;
+        for (int k = 0; k < 25; ++k) mx = mx > opt.mat[k] ? mx : opt.mat[k];
+        max_ins = (int)((double)(qlen * mx + end_bonus - o_ins) / e_ins + 1.);
+        max_ins = max_ins > 1 ? max_ins : 1;
+        w = w < max_ins ? w : max_ins;
+        max_del = (int)((double)(qlen * mx + end_bonus - o_del) / e_del + 1.);
+        max_del = max_del > 1 ? max_del : 1;
+        w = w < max_del ? w : max_del;
+    }
+    max = h0; max_i = max_j = -1; max_ie = -1; gscore = -1; max_off = 0;
+    beg = 0; end = qlen;
+    int tch = 4;
+    for (i = 0; i < tlen; ++i) {
+        if ((i & 63) == 0) { int ii = i + lane; tch = ii < tlen ? ref_base2(ix, t0 + (int64_t)tstep * ii) : 4; }
+        const int tb = wave_readlane(tch, i & 63);
+        const int ms0 = opt.mat[tb * 5], ms1 = opt.mat[tb * 5 + 1], ms2 = opt.mat[tb * 5 + 2], ms3 = opt.mat[tb * 5 + 3], ms4 = opt.mat[tb * 5 + 4];
+        int m = 0, mj = -1, h1, h1i;
+        if (beg < i - w) beg = i - w;
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        if (beg == 0) { h1i = h0 - (o_del + e_del * (i + 1)); if (h1i < 0) h1i = 0; }
+        else h1i = 0;
+        h1 = h1i;
+        int hnew[C], enew[C];
+        int fcarry = NEG_INF_I32, prev_last = 0;
+#pragma unroll
+        for (int t = 0; t < C; ++t) {
+            const int c0 = t * WAVE, j = c0 + lane;
+            const bool act = j >= beg && j < end;
+            const int Mp = ehh[t], e = ehe[t];
+            const int sc = qc[t] == 0 ? ms0 : qc[t] == 1 ? ms1 : qc[t] == 2 ? ms2 : qc[t] == 3 ? ms3 : ms4;
+            const int M = act && Mp ? Mp + sc : 0;
+            int tt = M - oe_ins; tt = tt > 0 ? tt : 0;
+            const int U = act ? tt + j * e_ins : NEG_INF_I32;
+            const int P = dpp_prefix_max(U, NEG_INF_I32);
+            const int Pex = dpp_shr1(P, NEG_INF_I32);
+            int f = fcarry - (j - c0) * e_ins;
+            { int g = Pex - (j - 1) * e_ins; f = f > g ? f : g; }
+            if (j == beg) f = 0;
+            int h = M > e ? M : e;
+            h = h > f ? h : f;
+            if (!act) h = -1;
+            const int mc = wave_readlane(dpp_prefix_max(h, -1), 63);
+            const unsigned long long bal = wave_ballot(act && h == mc);
+            if (bal && mc >= m) { m = mc; mj = c0 + 63 - __clzll((long long)bal); }
+            {
+                const int Plast = wave_readlane(P, 63);
+                const int f1 = fcarry - WAVE * e_ins, f2 = Plast - (c0 + 63) * e_ins;
+                fcarry = f1 > f2 ? f1 : f2;
+            }
+            int t2 = M - oe_del; t2 = t2 > 0 ? t2 : 0;
+            int en = e - e_del; en = en > t2 ? en : t2;
+            hnew[t] = h; enew[t] = en;
+            // h of column end-1 (needed below) lives in this chunk?
+            if (end > beg && ((end - 1) >> 6) == t) h1 = wave_readlane(h, (end - 1) & 63);
+        }
+#pragma unroll
+        for (int t = 0; t < C; ++t) {                      // in-place row update: eh[beg].h = h1i, eh[j+1].h = H(i,j), eh[end].e = 0
+            const int j = t * WAVE + lane;
+            const int hsh = dpp_shr1(hnew[t], prev_last);
+            prev_last = wave_readlane(hnew[t], 63);
+            if (end > beg) {
+                if (j == beg) ehh[t] = h1i;
+                else if (j > beg && j <= end) ehh[t] = hsh;
+                if (j >= beg && j < end) ehe[t] = enew[t];
+                else if (j == end) ehe[t] = 0;
+            } else if (j == end) { ehh[t] = h1i; ehe[t] = 0; }
+        }
+        if (end > beg) n_cells += (unsigned long long)(end - beg);
+        {
+            const int jafter = end > beg ? end : beg;
+            if (jafter == qlen) {
+                max_ie = gscore > h1 ? max_ie : i;
+                gscore = gscore > h1 ? gscore : h1;
+            }
+        }
+        if (m == 0) break;
+        if (m > max) {
+            max = m; max_i = i; max_j = mj;
+            int d = mj - i; d = d < 0 ? -d : d;
+            max_off = max_off > d ? max_off : d;
+        } else if (zdrop > 0) {
+            if (i - max_i > mj - max_j) {
+                if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
+            } else {
+                if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
+            }
+        }
+        {   // shrink the window to the non-zero span of the row just written
+            int nb = end, jl = -2;
+#pragma unroll
+            for (int t = 0; t < C; ++t) {
+                const int j = t * WAVE + lane;
+                const unsigned long long nz = wave_ballot((ehh[t] != 0 || ehe[t] != 0) && j >= beg && j < end);
+                if (nz && nb == end) nb = t * WAVE + __ffsll((long long)nz) - 1;
+            }
+            beg = nb;
+#pragma unroll
+            for (int t = C - 1; t >= 0; --t) {
+                const int j = t * WAVE + lane;
+                const unsigned long long nz = wave_ballot((ehh[t] != 0 || ehe[t] != 0) && j >= beg && j <= end);
+                if (nz && jl == -2) jl = t * WAVE + 63 - __clzll((long long)nz);
+            }
+            if (jl == -2) jl = beg - 1;
+            end = jl + 2 < qlen ? jl + 2 : qlen;
+        }
+    }
+    ExtRes r;
+    r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+    return r;
+}
+
+// picks the register-resident form when the query fits
+static __device__ ExtRes extend_any(const DevIndex& ix, const MemOpt& opt, const ExtLds& L, int lane,
+                                    int qlen, int q0, int qstep, int tlen, int64_t t0, int tstep,
+                                    int w, int end_bonus, int zdrop, int h0, unsigned long long& n_cells)
+{
+    if (qlen + 1 <= WAVE) return extend_wave_reg<1>(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
+    if (qlen + 1 <= 2 * WAVE) return extend_wave_reg<2>(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
+    if (qlen + 1 <= 3 * WAVE) return extend_wave_reg<3>(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
+    return extend_wave(ix, opt, L, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
+}
+
 struct U64Lt { __device__ bool operator()(uint64_t a, uint64_t b) const { return a < b; } };
 
 #define MAX_BAND_TRY 2
@@ -262,7 +412,7 @@ __global__ void __launch_bounds__(64) k_extend(DevIndex ix, MemOpt opt, TileView
                 for (i = 0; i < MAX_BAND_TRY; ++i) {
                     int prev = a.score;
                     aw0 = opt.w << i;
-                    e = extend_wave(ix, opt, L, lane, s.qbeg, s.qbeg - 1, -1, (int)tmp, s.rbeg - 1, -1,
+                    e = extend_any(ix, opt, L, lane, s.qbeg, s.qbeg - 1, -1, (int)tmp, s.rbeg - 1, -1,
                                     aw0, opt.pen_clip5, opt.zdrop, s.len * opt.a, n_cells);
                     a.score = e.score;
                     if (a.score == prev || e.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
@@ -283,7 +433,7 @@ __global__ void __launch_bounds__(64) k_extend(DevIndex ix, MemOpt opt, TileView
                 for (i = 0; i < MAX_BAND_TRY; ++i) {
                     int prev = a.score;
                     aw1 = opt.w << i;
-                    e = extend_wave(ix, opt, L, lane, l_query - qe, qe, 1, (int)(rmax1 - rmax0 - re), rmax0 + re, 1,
+                    e = extend_any(ix, opt, L, lane, l_query - qe, qe, 1, (int)(rmax1 - rmax0 - re), rmax0 + re, 1,
                                     aw1, opt.pen_clip3, opt.zdrop, sc0, n_cells);
                     a.score = e.score;
                     if (a.score == prev || e.max_off < (aw1 >> 1) + (aw1 >> 2)) break;

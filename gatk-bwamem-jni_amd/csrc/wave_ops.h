@@ -28,3 +28,27 @@ static __device__ inline int wave_bcast(int v, int src) { return __shfl(v, src);
 static __device__ inline unsigned long long wave_ballot(int pred) { return __ballot(pred); }
 
 static __device__ inline bool wave_any(int pred) { return __ballot(pred) != 0ull; }
+
+// ---- DPP (data-parallel primitives) forms: cross-lane moves folded into VALU instructions, no LDS round trip.
+// gfx9 controls: row_shr:n = 0x110+n (within a 16-lane row), wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_WAVE_SHR1 0x138
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+
+// inclusive prefix maximum over the 64 lanes; lanes without a source keep their own value (identity = neg)
+static __device__ inline int dpp_prefix_max(int v, int neg)
+{
+    int t;
+    t = __builtin_amdgcn_update_dpp(neg, v, DPP_ROW_SHR(1), 0xf, 0xf, false); v = v > t ? v : t;
+    t = __builtin_amdgcn_update_dpp(neg, v, DPP_ROW_SHR(2), 0xf, 0xf, false); v = v > t ? v : t;
+    t = __builtin_amdgcn_update_dpp(neg, v, DPP_ROW_SHR(4), 0xf, 0xf, false); v = v > t ? v : t;
+    t = __builtin_amdgcn_update_dpp(neg, v, DPP_ROW_SHR(8), 0xf, 0xf, false); v = v > t ? v : t;
+    t = __builtin_amdgcn_update_dpp(neg, v, DPP_ROW_BCAST15, 0xa, 0xf, false); v = v > t ? v : t;
+    t = __builtin_amdgcn_update_dpp(neg, v, DPP_ROW_BCAST31, 0xc, 0xf, false); v = v > t ? v : t;
+    return v;
+}
+// lane l <- lane l-1; lane 0 <- fill
+static __device__ inline int dpp_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHR1, 0xf, 0xf, false); }
+// value of a (wave-uniform) lane as a scalar
+static __device__ inline int wave_readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }

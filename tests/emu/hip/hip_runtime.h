@@ -75,6 +75,32 @@ static inline unsigned long long __ballot(int pred)
 }
 static inline void __syncthreads() { emu::sync_block(); }
 
+// DPP subset used by wave_ops.h (gfx9 controls row_shr:n, wave_shr:1, row_bcast:15, row_bcast:31)
+static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+{
+    uint64_t* s = emu::wave_slots();
+    int lane = threadIdx.x & 63, row = lane >> 4, in_row = lane & 15;
+    s[lane] = (uint32_t)src;
+    emu::sync_wave();
+    int from = -1;
+    if (ctrl >= 0x111 && ctrl <= 0x11f) { int n = ctrl - 0x110; from = in_row >= n ? lane - n : -1; }
+    else if (ctrl == 0x138) from = lane >= 1 ? lane - 1 : -1;
+    else if (ctrl == 0x142) from = row >= 1 ? (row << 4) - 1 : -1;
+    else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;
+    else { fprintf(stderr, "emu: unsupported DPP control 0x%x\n", ctrl); abort(); }
+    bool enabled = (row_mask >> row & 1) && (bank_mask >> (in_row >> 2) & 1);
+    int r = old;
+    if (enabled) {
+        if (from >= 0 && (emu::wave_alive_mask() >> from & 1)) r = (int)(uint32_t)s[from];
+        else if (bound_ctrl) r = 0;
+    }
+    emu::sync_wave();
+    return r;
+}
+#define __builtin_amdgcn_update_dpp emu_update_dpp
+static inline int emu_readlane(int v, int lane) { return __shfl(v, lane); }
+#define __builtin_amdgcn_readlane emu_readlane
+
 template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 static inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
 

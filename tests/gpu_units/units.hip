@@ -13,7 +13,7 @@ struct PairXLt { __device__ bool operator()(const PairX& a, const PairX& b) cons
 
 __global__ void k_unit_sort_pairs(PairX* a, int n) { if (threadIdx.x == 0 && blockIdx.x == 0) ks_introsort((size_t)n, a, PairXLt()); }
 
-__global__ void __launch_bounds__(64) k_unit_extend(DevIndex ix, MemOpt opt, const uint8_t* query, int qlen, int tlen, int w, int end_bonus, int zdrop, int h0, int* out)
+__global__ void __launch_bounds__(64) k_unit_extend(DevIndex ix, MemOpt opt, const uint8_t* query, int qlen, int tlen, int w, int end_bonus, int zdrop, int h0, int* out, int force_lds)
 {
     HIP_DYNAMIC_SHARED(int32_t, smem)
     const int cap = qlen + 2, lane = threadIdx.x;
@@ -24,7 +24,8 @@ __global__ void __launch_bounds__(64) k_unit_extend(DevIndex ix, MemOpt opt, con
     for (int j = lane; j < qlen; j += WAVE) sq[j] = query[j];
     __syncthreads();
     unsigned long long n_cells = 0;
-    ExtRes r = extend_wave(ix, opt, L, lane, qlen, 0, 1, tlen, 0, 1, w, end_bonus, zdrop, h0, n_cells);
+    ExtRes r = force_lds ? extend_wave(ix, opt, L, lane, qlen, 0, 1, tlen, 0, 1, w, end_bonus, zdrop, h0, n_cells)
+                         : extend_any(ix, opt, L, lane, qlen, 0, 1, tlen, 0, 1, w, end_bonus, zdrop, h0, n_cells);
     if (lane == 0) { out[0] = r.score; out[1] = r.qle; out[2] = r.tle; out[3] = r.gtle; out[4] = r.gscore; out[5] = r.max_off; }
 }
 
@@ -48,7 +49,7 @@ extern "C" int unit_sort_pairs(int n, uint64_t* xy)
 
 // target is packed 2 bit/base into a throw-away "reference" so extend_wave reads it exactly as in production
 extern "C" int unit_extend(const uint8_t* query, int qlen, const uint8_t* target, int tlen, const MemOpt* opt,
-                           int w, int end_bonus, int zdrop, int h0, int* out6)
+                           int w, int end_bonus, int zdrop, int h0, int* out6, int force_lds)
 {
     std::vector<uint8_t> pac((size_t)tlen / 4 + 2, 0);
     for (int i = 0; i < tlen; ++i) pac[i >> 2] |= (uint8_t)(target[i] << ((~i & 3) << 1));
@@ -59,7 +60,7 @@ extern "C" int unit_extend(const uint8_t* query, int qlen, const uint8_t* target
     DevIndex ix; memset(&ix, 0, sizeof ix);
     ix.pac = d_pac; ix.l_pac = tlen;
     size_t cap = (size_t)qlen + 2, shmem = 3 * cap * 4 + ((cap + 15) & ~(size_t)15);
-    hipLaunchKernelGGL(k_unit_extend, dim3(1), dim3(64), shmem, 0, ix, *opt, d_q, qlen, tlen, w, end_bonus, zdrop, h0, d_out);
+    hipLaunchKernelGGL(k_unit_extend, dim3(1), dim3(64), shmem, 0, ix, *opt, d_q, qlen, tlen, w, end_bonus, zdrop, h0, d_out, force_lds);
     int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -1;
     hipMemcpy(out6, d_out, 24, hipMemcpyDeviceToHost);
     hipFree(d_pac); hipFree(d_q); hipFree(d_out);

@@ -17,7 +17,7 @@ def _load(flavour):
     subprocess.run(["make", "-s", "-C", UNITS] + (["emu"] if flavour == "emu" else []), check=True)
     lib = ctypes.CDLL(os.path.join(UNITS, "_build", "libunits_%s.so" % flavour))
     lib.unit_sort_pairs.argtypes = [ctypes.c_int, ctypes.c_void_p]
-    lib.unit_extend.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    lib.unit_extend.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
     return lib
 
 
@@ -73,8 +73,9 @@ def _check_extend(units, oracle, n_cases, max_q):
                   ctypes.byref(want, 0), ctypes.byref(want, 4), ctypes.byref(want, 8), ctypes.byref(want, 12), ctypes.byref(want, 16))
         got = (ctypes.c_int * 6)()
         ob = ctypes.create_string_buffer(bytes(opts), 168)
-        assert units.unit_extend(q.tobytes(), qlen, t.tobytes(), tlen, ob, w, end_bonus, zdrop, h0, got) == 0
-        assert list(got) == [ws, want[0], want[1], want[2], want[3], want[4]], (it, qlen, tlen, kw, w, zdrop, h0)
+        for force_lds in (0, 1):          # the register-resident form (when the query fits) and the general LDS form
+            assert units.unit_extend(q.tobytes(), qlen, t.tobytes(), tlen, ob, w, end_bonus, zdrop, h0, got, force_lds) == 0
+            assert list(got) == [ws, want[0], want[1], want[2], want[3], want[4]], (it, force_lds, qlen, tlen, kw, w, zdrop, h0)
 
 
 def test_units_emu_sort(oracle):
@@ -82,7 +83,7 @@ def test_units_emu_sort(oracle):
 
 
 def test_units_emu_extend(oracle):
-    _check_extend(_load("emu"), oracle, 40, 150)
+    _check_extend(_load("emu"), oracle, 60, 230)
 
 
 @pytest.mark.gpu
