@@ -243,9 +243,9 @@ def main():
     if rank == 0:
         value = world * R * args.steps / elapsed
         kern = dict(encode=st.ms_encode, seed=st.ms_seed, sa=st.ms_sa, chain=st.ms_chain, extend=st.ms_extend, post=st.ms_post, final=st.ms_final, pack=st.ms_pack, other=st.ms_other)
-        # roofline of the occurrence-table gather kernel (k_seed): 2 x 64-byte occ lines per interval extension
+        # roofline of the occurrence-table gather kernel (k_seed): 2 x 32-byte occ blocks (device layout) per interval extension
         n_launch = max(1, st.n_launch_seed)
-        alg_bytes = 128.0 * st.n_ext / n_launch
+        alg_bytes = 64.0 * st.n_ext / n_launch
         avg_s = st.ms_seed * 1e-3 / n_launch
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         out = {

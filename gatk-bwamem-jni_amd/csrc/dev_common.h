@@ -21,6 +21,16 @@ DEV void cnt_word(uint32_t x, int n, uint32_t& c1, uint32_t& c2, uint32_t& c3)
     c1 += __popc(~hi & lo);
 }
 
+// absolute counts of A,C,G,T before block b from its packed 16-byte count word
+DEV void occ_unpack(const uint4& c, uint64_t b, uint64_t& a0, uint64_t& a1, uint64_t& a2, uint64_t& a3)
+{
+    const uint64_t lo = (uint64_t)c.y << 32 | c.x, hi = (uint64_t)c.w << 32 | c.z;
+    a1 = lo & 0xffffffffffull;
+    a2 = (lo >> 40) | ((hi & 0xffff) << 24);
+    a3 = (hi >> 16) & 0xffffffffffull;
+    a0 = (b << 6) - a1 - a2 - a3;
+}
+
 // occ(k, .) for all four symbols: # of c in BWT$[0..k] (k in sentinel-inclusive coordinates)
 DEV void occ4(const DevIndex& ix, uint64_t k, uint64_t cnt[4])
 {
@@ -29,15 +39,16 @@ DEV void occ4(const DevIndex& ix, uint64_t k, uint64_t cnt[4])
     const uint64_t b = k >> 6;
     const uint4* p = ix.occ + 2 * b;                           // one 32-byte block
     const uint4 c = p[0], s = p[1];
-    const uint64_t* sp = ix.occ_super + 4 * (b >> (OCC_SUPER_SHIFT - 6));
     const int n = (int)(k & 63) + 1;                           // symbols of this block to count
     uint32_t c1 = 0, c2 = 0, c3 = 0;
     cnt_word(s.x, n, c1, c2, c3);       cnt_word(s.y, n - 16, c1, c2, c3);
     cnt_word(s.z, n - 32, c1, c2, c3);  cnt_word(s.w, n - 48, c1, c2, c3);
-    cnt[0] = sp[0] + c.x + (uint32_t)(n - (int)(c1 + c2 + c3));
-    cnt[1] = sp[1] + c.y + c1;
-    cnt[2] = sp[2] + c.z + c2;
-    cnt[3] = sp[3] + c.w + c3;
+    uint64_t a0, a1, a2, a3;
+    occ_unpack(c, b, a0, a1, a2, a3);
+    cnt[0] = a0 + (uint32_t)(n - (int)(c1 + c2 + c3));
+    cnt[1] = a1 + c1;
+    cnt[2] = a2 + c2;
+    cnt[3] = a3 + c3;
 }
 
 // occ(k,.) and occ(l,.) for k <= l.  When both ranks fall into the same 64-symbol block (the common case once an
@@ -49,14 +60,14 @@ DEV void occ4_pair(const DevIndex& ix, uint64_t k, uint64_t l, uint64_t tk[4], u
     const uint64_t b = kk >> 6;
     const uint4* p = ix.occ + 2 * b;
     const uint4 c = p[0], s = p[1];
-    const uint64_t* sp = ix.occ_super + 4 * (b >> (OCC_SUPER_SHIFT - 6));
     const int nk = (int)(kk & 63) + 1, nl = (int)(ll & 63) + 1;
     uint32_t a1 = 0, a2 = 0, a3 = 0, b1 = 0, b2 = 0, b3 = 0;
     cnt_word(s.x, nk, a1, a2, a3);       cnt_word(s.x, nl, b1, b2, b3);
     cnt_word(s.y, nk - 16, a1, a2, a3);  cnt_word(s.y, nl - 16, b1, b2, b3);
     cnt_word(s.z, nk - 32, a1, a2, a3);  cnt_word(s.z, nl - 32, b1, b2, b3);
     cnt_word(s.w, nk - 48, a1, a2, a3);  cnt_word(s.w, nl - 48, b1, b2, b3);
-    const uint64_t c0 = sp[0] + c.x, c1 = sp[1] + c.y, c2 = sp[2] + c.z, c3 = sp[3] + c.w;
+    uint64_t c0, c1, c2, c3;
+    occ_unpack(c, b, c0, c1, c2, c3);
     tk[0] = c0 + (uint32_t)(nk - (int)(a1 + a2 + a3)); tk[1] = c1 + a1; tk[2] = c2 + a2; tk[3] = c3 + a3;
     tl[0] = c0 + (uint32_t)(nl - (int)(b1 + b2 + b3)); tl[1] = c1 + b1; tl[2] = c2 + b2; tl[3] = c3 + b3;
 }
@@ -102,14 +113,15 @@ DEV uint64_t sa_lookup(const DevIndex& ix, uint64_t k, uint32_t& n_lf)
         const uint64_t x = k - (k > ix.primary), b = x >> 6;
         const uint4* p = ix.occ + 2 * b;
         const uint4 cv = p[0], s = p[1];
-        const uint64_t* sp = ix.occ_super + 4 * (b >> (OCC_SUPER_SHIFT - 6));
         const int off = (int)(x & 63);
         const uint32_t w = (off >> 4) == 0 ? s.x : (off >> 4) == 1 ? s.y : (off >> 4) == 2 ? s.z : s.w;
         const int c = (int)(w >> ((~off & 15) << 1) & 3);       // BWT symbol at rank k
         uint32_t c1 = 0, c2 = 0, c3 = 0;
         cnt_word(s.x, off + 1, c1, c2, c3);  cnt_word(s.y, off - 15, c1, c2, c3);
         cnt_word(s.z, off - 31, c1, c2, c3); cnt_word(s.w, off - 47, c1, c2, c3);
-        const uint64_t base = c == 0 ? sp[0] + cv.x : c == 1 ? sp[1] + cv.y : c == 2 ? sp[2] + cv.z : sp[3] + cv.w;
+        uint64_t a0, a1, a2, a3;
+        occ_unpack(cv, b, a0, a1, a2, a3);
+        const uint64_t base = c == 0 ? a0 : c == 1 ? a1 : c == 2 ? a2 : a3;
         const uint32_t add = c == 0 ? (uint32_t)(off + 1 - (int)(c1 + c2 + c3)) : c == 1 ? c1 : c == 2 ? c2 : c3;
         k = ix.L2[c] + base + add;
     }

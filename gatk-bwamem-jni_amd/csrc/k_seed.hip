@@ -147,12 +147,25 @@ __global__ void k_encode(uint8_t* seq, int64_t n_bytes)
 
 // mem_collect_intv (row a6) + the per-read bookkeeping mem_chain does before looking up the SA:
 // l_rep (repetitive fraction numerator) and the number of occurrences each interval contributes.
-__global__ void k_seed(DevIndex ix, MemOpt opt, TileView tv)
+// LDSQ: the 64 reads of the block are staged in LDS with one coalesced copy, so the per-step base look-ups of the
+// search do not compete with the occ gathers for vector-memory requests (used when 64 reads fit 24 KB).
+template <bool LDSQ>
+__global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView tv)
 {
+    HIP_DYNAMIC_SHARED(uint8_t, sq)
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_ext = 0;
+    int64_t base_off = 0;
+    if (LDSQ) {
+        const int r0 = blockIdx.x * blockDim.x;
+        const int r1 = r0 + 64 < tv.n_reads ? r0 + 64 : tv.n_reads;
+        base_off = tv.seq_off[r0];
+        const int nbytes = (int)(tv.seq_off[r1] - base_off);
+        for (int k = threadIdx.x; k < nbytes; k += 64) sq[k] = tv.seq[base_off + k];
+        __syncthreads();
+    }
     if (r < tv.n_reads) {
-        const uint8_t* q = tv.seq + tv.seq_off[r];
+        const uint8_t* q = LDSQ ? (const uint8_t*)sq + (tv.seq_off[r] - base_off) : tv.seq + tv.seq_off[r];
         int len = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
         // scratch of wave-group g = r/64: [2 vectors][smem_cap entries][64 lanes]
         uint4* sc = (uint4*)tv.smem_scratch + ((size_t)(r >> 6) * 2 * tv.smem_cap) * 64 + (r & 63);
@@ -282,33 +295,26 @@ __global__ void k_sa(DevIndex ix, MemOpt opt, TileView tv, int64_t n_occ)
 }
 
 // image occ/bwt layout (128-symbol blocks: 4 x u64 counts + 8 x u32 symbols) -> device layout (see bwamem_types.h)
-__global__ void k_build_occ64(const uint32_t* bwt, uint64_t n_blocks, uint64_t n_super, uint4* occ, uint64_t* super)
+__global__ void k_build_occ64(const uint32_t* bwt, uint64_t n_blocks, uint4* occ)
 {
     uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < n_super) {                                          // absolute counts at symbol b * 2^20
-        const uint64_t* src = (const uint64_t*)(bwt + ((b << OCC_SUPER_SHIFT) >> 7 << 4));
-        for (int c = 0; c < 4; ++c) super[4 * b + c] = src[c];
-    }
     if (b >= n_blocks) return;
     const uint32_t* blk = bwt + (b >> 1 << 4);                  // the 128-symbol source block
     const uint64_t* cnt = (const uint64_t*)blk;
     const uint32_t* sym = blk + 8 + ((b & 1) << 2);
-    const uint64_t* sp = (const uint64_t*)(bwt + (((b >> (OCC_SUPER_SHIFT - 6)) << OCC_SUPER_SHIFT) >> 7 << 4));
     uint32_t c1 = 0, c2 = 0, c3 = 0;
     if (b & 1) for (int i = 0; i < 4; ++i) cnt_word(blk[8 + i], 16, c1, c2, c3);   // first half of the source block
+    const uint64_t C = cnt[1] + c1, G = cnt[2] + c2, T = cnt[3] + c3;
+    const uint64_t lo = (C & 0xffffffffffull) | (G << 40), hi = ((G >> 24) & 0xffff) | ((T & 0xffffffffffull) << 16);
     uint4 c, s;
-    c.x = (uint32_t)(cnt[0] - sp[0]) + ((b & 1) ? 64 - (c1 + c2 + c3) : 0);
-    c.y = (uint32_t)(cnt[1] - sp[1]) + c1;
-    c.z = (uint32_t)(cnt[2] - sp[2]) + c2;
-    c.w = (uint32_t)(cnt[3] - sp[3]) + c3;
+    c.x = (uint32_t)lo; c.y = (uint32_t)(lo >> 32); c.z = (uint32_t)hi; c.w = (uint32_t)(hi >> 32);
     s.x = sym[0]; s.y = sym[1]; s.z = sym[2]; s.w = sym[3];
     occ[2 * b] = c; occ[2 * b + 1] = s;
 }
 
-void launch_build_occ64(hipStream_t st, const uint32_t* bwt, uint64_t n_blocks, uint64_t n_super, uint4* occ, uint64_t* super)
+void launch_build_occ64(hipStream_t st, const uint32_t* bwt, uint64_t n_blocks, uint4* occ)
 {
-    uint64_t n = n_blocks > n_super ? n_blocks : n_super;
-    hipLaunchKernelGGL(k_build_occ64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bwt, n_blocks, n_super, occ, super);
+    hipLaunchKernelGGL(k_build_occ64, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, bwt, n_blocks, occ);
 }
 
 void launch_encode(hipStream_t st, uint8_t* seq, int64_t n_bytes)
@@ -321,7 +327,9 @@ void launch_encode(hipStream_t st, uint8_t* seq, int64_t n_bytes)
 void launch_seed(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv)
 {
     if (tv.n_reads <= 0) return;
-    hipLaunchKernelGGL(k_seed, dim3((tv.n_reads + 63) / 64), dim3(64), 0, st, ix, opt, tv);
+    const size_t lds = (size_t)64 * ((size_t)tv.max_len + 1) + 64;
+    if (lds <= 24576) hipLaunchKernelGGL(k_seed<true>, dim3((tv.n_reads + 63) / 64), dim3(64), lds, st, ix, opt, tv);
+    else hipLaunchKernelGGL(k_seed<false>, dim3((tv.n_reads + 63) / 64), dim3(64), 0, st, ix, opt, tv);
 }
 void launch_scan(hipStream_t st, const int32_t* in, int64_t* out, int n)
 {

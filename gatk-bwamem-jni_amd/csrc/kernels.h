@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "bwamem_types.h"
 
-void launch_build_occ64(hipStream_t st, const uint32_t* bwt, uint64_t n_blocks, uint64_t n_super, uint4* occ, uint64_t* super);
+void launch_build_occ64(hipStream_t st, const uint32_t* bwt, uint64_t n_blocks, uint4* occ);
 void launch_encode(hipStream_t st, uint8_t* seq, int64_t n_bytes);
 void launch_seed(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 void launch_scan(hipStream_t st, const int32_t* in, int64_t* out, int n);

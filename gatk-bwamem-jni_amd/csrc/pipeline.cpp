@@ -119,7 +119,7 @@ struct bwaidx_s {
     HostIndex h;
     int device = 0;
     DevIndex d;
-    DevBuf d_occ, d_super, d_sa, d_pac, d_ann_off, d_ann_len, d_ann_alt, d_name_off, d_names, d_log;
+    DevBuf d_occ, d_sa, d_pac, d_ann_off, d_ann_len, d_ann_alt, d_name_off, d_names, d_log;
     std::mutex mu;                  // one call at a time per index/device
     Workspace ws;
     std::vector<Workspace*> extra_ws;   // further tiles in flight (one stream + host thread each)
@@ -148,11 +148,11 @@ static bool upload_index(bwaidx_s* ix)
     {   // upload the image's occ/bwt array to a scratch buffer and re-block it into the device layout
         DevBuf tmp;
         size_t bwt_bytes = ((size_t)h.bwt_size * 4 + 255) & ~(size_t)63;
-        const uint64_t n_blocks = (h.seq_len + 63) / 64 + 1, n_super = (h.seq_len >> OCC_SUPER_SHIFT) + 1;
-        if (!tmp.ensure(bwt_bytes) || !ix->d_occ.ensure((size_t)n_blocks * 32 + 64) || !ix->d_super.ensure((size_t)n_super * 32 + 64)) { tmp.release(); return false; }
+        const uint64_t n_blocks = (h.seq_len + 63) / 64 + 1;
+        if (!tmp.ensure(bwt_bytes) || !ix->d_occ.ensure((size_t)n_blocks * 32 + 64)) { tmp.release(); return false; }
         HIP_OK(hipMemset(tmp.p, 0, tmp.bytes));
         HIP_OK(hipMemcpy(tmp.p, h.bwt, (size_t)h.bwt_size * 4, hipMemcpyHostToDevice));
-        launch_build_occ64(0, tmp.as<uint32_t>(), n_blocks, n_super, ix->d_occ.as<uint4>(), ix->d_super.as<uint64_t>());
+        launch_build_occ64(0, tmp.as<uint32_t>(), n_blocks, ix->d_occ.as<uint4>());
         HIP_OK(hipDeviceSynchronize());
         tmp.release();
     }
@@ -181,7 +181,7 @@ static bool upload_index(bwaidx_s* ix)
     }
     DevIndex& d = ix->d;
     memset(&d, 0, sizeof d);
-    d.occ = ix->d_occ.as<uint4>(); d.occ_super = ix->d_super.as<uint64_t>(); d.sa = ix->d_sa.as<uint64_t>(); d.pac = ix->d_pac.as<uint8_t>();
+    d.occ = ix->d_occ.as<uint4>(); d.sa = ix->d_sa.as<uint64_t>(); d.pac = ix->d_pac.as<uint8_t>();
     d.ann_offset = ix->d_ann_off.as<int64_t>(); d.ann_len = ix->d_ann_len.as<int32_t>(); d.ann_is_alt = ix->d_ann_alt.as<int32_t>();
     d.ann_name_off = ix->d_name_off.as<int32_t>(); d.names = ix->d_names.as<char>(); d.log_tab = ix->d_log.as<double>();
     d.primary = h.primary; for (int i = 0; i < 5; ++i) d.L2[i] = h.L2[i];
@@ -192,7 +192,7 @@ static bool upload_index(bwaidx_s* ix)
 static void free_index(bwaidx_s* ix)
 {
     (void)hipSetDevice(ix->device);
-    DevBuf* all[] = { &ix->d_occ, &ix->d_super, &ix->d_sa, &ix->d_pac, &ix->d_ann_off, &ix->d_ann_len, &ix->d_ann_alt, &ix->d_name_off, &ix->d_names, &ix->d_log };
+    DevBuf* all[] = { &ix->d_occ, &ix->d_sa, &ix->d_pac, &ix->d_ann_off, &ix->d_ann_len, &ix->d_ann_alt, &ix->d_name_off, &ix->d_names, &ix->d_log };
     for (DevBuf* b : all) b->release();
     ix->ws.release();
     for (Workspace* w : ix->extra_ws) { w->release(); delete w; }
