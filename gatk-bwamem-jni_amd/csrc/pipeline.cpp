@@ -249,12 +249,14 @@ static void verbose_sync(Workspace& ws, const char* what)
 #define TIMED(ws, id, call) do { timed_begin(ws, id); call; timed_end(ws); if (verbose()) verbose_sync(ws, #call); } while (0)
 
 // ------------------------------------------------------------------------------------------ tile loop
-static int64_t post_bytes_per_read(int L, const MemOpt& opt)
+// per-read scratch of the one-lane-per-read post stages: (h,e) row, CIGAR, MD and -- only where the scalar global
+// alignment with traceback still runs there (paired-end) -- the traceback matrix
+static int64_t post_bytes_per_read(int L, const MemOpt& opt, bool with_traceback = true)
 {
     int64_t ncol = std::min<int64_t>(L, 2 * ((int64_t)opt.w << 2) + 1);
     int64_t tl = 3 * (int64_t)L + 64;
     int64_t fixed = (int64_t)2 * (L + 2) * 4 + (int64_t)(4 * L + 16) * 4 + (8 * L + 32);
-    return ((fixed + ncol * tl) + 63) & ~(int64_t)63;
+    return ((fixed + (with_traceback ? ncol * tl : 64)) + 63) & ~(int64_t)63;
 }
 
 
@@ -481,12 +483,12 @@ static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes
 struct TileSpec { uint32_t r0, r1; int L; };
 
 // cut the batch into tiles from a per-workspace device-memory budget (pairs are never split when even = true)
-static std::vector<TileSpec> plan_tiles(const bwamem_batch_s* b, const MemOpt& opt, bool even)
+static std::vector<TileSpec> plan_tiles(const bwamem_batch_s* b, const MemOpt& opt, bool even, bool with_traceback)
 {
     const char* env_t = getenv("BWAMEM_HIP_TILE");
     const char* env_gb = getenv("BWAMEM_HIP_TILE_GB");
-    const int64_t budget = (int64_t)(env_gb ? atoi(env_gb) : 20) << 30;
-    uint32_t max_T = env_t ? (uint32_t)atoi(env_t) : 262144u;
+    const int64_t budget = (int64_t)(env_gb ? atoi(env_gb) : 12) << 30;
+    uint32_t max_T = env_t ? (uint32_t)atoi(env_t) : 196608u;
     if (even) max_T = std::max(2u, max_T & ~1u);
     std::vector<TileSpec> tiles;
     uint32_t r0 = 0;
@@ -496,7 +498,7 @@ static std::vector<TileSpec> plan_tiles(const bwamem_batch_s* b, const MemOpt& o
         while (r1 < b->n_reads && r1 - r0 < max_T) {
             int len = (int)(b->h_off[r1 + 1] - b->h_off[r1] - 1);
             int L1 = std::max(L0, len);
-            int64_t pr = (int64_t)std::max(64, L1 + 8) * (sizeof(Intv) + 4) + 2 * (int64_t)(L1 + 2) * 16 + 512 + post_bytes_per_read(L1, opt) + 64 * 300;
+            int64_t pr = (int64_t)std::max(64, L1 + 8) * (sizeof(Intv) + 4) + 2 * (int64_t)(L1 + 2) * 16 + 512 + post_bytes_per_read(L1, opt, with_traceback) + 64 * 300;
             if (r1 > r0 + (even ? 1u : 0u) && pr * (int64_t)(r1 - r0 + 1) > budget && (!even || ((r1 - r0) & 1) == 0)) break;
             L0 = L1; ++r1;
         }
@@ -518,7 +520,7 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
     size_t zpool_hint = (size_t)64 << 20;
     for (;;) {
         if (++attempts > 8) { fprintf(stderr, "[bwamem_hip] tile could not be sized after 8 attempts\n"); return false; }
-        if (!ws.ensure_reads(T, L, intv_cap, out_cap, post_bytes_per_read(L, opt))) return false;
+        if (!ws.ensure_reads(T, L, intv_cap, out_cap, post_bytes_per_read(L, opt, false))) return false;
         if (!ws.ensure_seeds(std::max<int64_t>(ws.seed_cap, (int64_t)T * 16))) return false;
         if (!ws.ensure_jobs(std::max(job_cap_hint, std::max(1024, T / 4)), 4 * L + 16, zpool_hint)) return false;
         TileView tv = ws.view();
@@ -605,11 +607,11 @@ static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, b
     if (opt.flag & MEM_F_PE) return align_batch_pe(ix, opt, pes, b, read_id0);
     HIP_OK(hipStreamSynchronize(ws.stream));
     timed_collect(ws);
-    const std::vector<TileSpec> specs = plan_tiles(b, opt, false);
+    const std::vector<TileSpec> specs = plan_tiles(b, opt, false, false);
     for (const TileSpec& t : specs) if (t.L >= (1 << 17) - 1) { fprintf(stderr, "[bwamem_hip] reads of 131071 bases or more are not supported\n"); return false; }
     b->tiles.assign(specs.size(), TileOut());
     const char* env_s = getenv("BWAMEM_HIP_STREAMS");
-    int n_workers = std::max(1, std::min<int>((int)specs.size(), env_s ? atoi(env_s) : 3));
+    int n_workers = std::max(1, std::min<int>((int)specs.size(), env_s ? atoi(env_s) : 4));
     while ((int)ix->extra_ws.size() < n_workers - 1) ix->extra_ws.push_back(new Workspace());
     std::atomic<size_t> next(0);
     std::atomic<bool> failed(false);
