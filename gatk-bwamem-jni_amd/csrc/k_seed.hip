@@ -3,132 +3,81 @@
 //
 // Replaces, for the reference call at jnibwa.c:214, upstream bwamem.c mem_collect_intv and
 // bwt.c bwt_smem1 / bwt_seed_strategy1 / bwt_extend / bwt_2occ4 / bwt_sa (SURVEY.md rows
-// a2-a7).  One lane walks one read: every interval extension is two dependent random
-// 64-byte gathers, so throughput comes from the number of independent reads in flight per
-// CU, not from parallelism inside a read.
+// a2-a7).  One lane walks one read: every interval extension is a pair of dependent random
+// 32-byte gathers, so throughput comes from the number of lanes that have a gather in flight,
+// not from parallelism inside a read.
 #include "dev_common.h"
+#include "wave_ops.h"
 #include "kernels.h"
 
-// Per-read interval vectors live in global scratch laid out [entry][lane]: when the 64 reads of a wave push or
-// read entry e together, the wave touches one contiguous 2 KB span instead of 64 scattered lines.
-struct IntvVec {
-    Intv* a; int n; int cap; int stride;
-    __device__ Intv get(int i) const { return a[(size_t)i * stride]; }
-    __device__ void set(int i, const Intv& v) { a[(size_t)i * stride] = v; }
-    __device__ bool push(const Intv& v) { if (n >= cap) return false; a[(size_t)n * stride] = v; ++n; return true; }
+// The symbol words and packed counts of the two blocks an extension needs are requested together (four 16-byte
+// lane loads in flight), whether or not the two ranks share a block: one code path for the whole wave, and a repeated
+// block is a cache hit.  Same arithmetic as occ4 (dev_common.h).
+DEV void occ4_two(const DevIndex& ix, uint64_t k, uint64_t l, uint64_t tk[4], uint64_t tl[4])
+{
+    const bool zk = k == (uint64_t)-1, zl = l == (uint64_t)-1;
+    const uint64_t kk = zk ? 0 : k - (k >= ix.primary), ll = zl ? 0 : l - (l >= ix.primary);
+    const uint64_t bk = kk >> 6, bl = ll >> 6;
+    const uint4* pk = ix.occ + 2 * bk;
+    const uint4* pl = ix.occ + 2 * bl;
+    const uint4 ck = pk[0], sk = pk[1], cl = pl[0], sl = pl[1];
+    const int nk = (int)(kk & 63) + 1, nl = (int)(ll & 63) + 1;
+    uint32_t a1 = 0, a2 = 0, a3 = 0, b1 = 0, b2 = 0, b3 = 0;
+    cnt_word(sk.x, nk, a1, a2, a3);       cnt_word(sl.x, nl, b1, b2, b3);
+    cnt_word(sk.y, nk - 16, a1, a2, a3);  cnt_word(sl.y, nl - 16, b1, b2, b3);
+    cnt_word(sk.z, nk - 32, a1, a2, a3);  cnt_word(sl.z, nl - 32, b1, b2, b3);
+    cnt_word(sk.w, nk - 48, a1, a2, a3);  cnt_word(sl.w, nl - 48, b1, b2, b3);
+    uint64_t c0, c1, c2, c3, d0, d1, d2, d3;
+    occ_unpack(ck, bk, c0, c1, c2, c3);
+    occ_unpack(cl, bl, d0, d1, d2, d3);
+    tk[0] = zk ? 0 : c0 + (uint32_t)(nk - (int)(a1 + a2 + a3)); tk[1] = zk ? 0 : c1 + a1; tk[2] = zk ? 0 : c2 + a2; tk[3] = zk ? 0 : c3 + a3;
+    tl[0] = zl ? 0 : d0 + (uint32_t)(nl - (int)(b1 + b2 + b3)); tl[1] = zl ? 0 : d1 + b1; tl[2] = zl ? 0 : d2 + b2; tl[3] = zl ? 0 : d3 + b3;
+}
+
+// bwt_extend for one symbol, both directions through one code path (cf. extend_one in dev_common.h; this form always
+// issues the loads of both blocks at once).  is_back = 1: the interval of bP for b = c; is_back = 0: upstream's ok[c]
+// of bwt_extend(..., 0), i.e. the interval of P followed by base 3 - c.
+DEV void extend_sm(const DevIndex& ix, uint64_t x0, uint64_t x1, uint64_t size, int c, bool is_back, uint64_t& o0, uint64_t& o1, uint64_t& osz)
+{
+    const uint64_t xa = is_back ? x0 : x1, xb = is_back ? x1 : x0;
+    uint64_t tk[4], tl[4];
+    occ4_two(ix, xa - 1, xa - 1 + size, tk, tl);
+    const uint64_t s0 = tl[0] - tk[0], s1 = tl[1] - tk[1], s2 = tl[2] - tk[2], s3 = tl[3] - tk[3];
+    const uint64_t tkc = c == 0 ? tk[0] : c == 1 ? tk[1] : c == 2 ? tk[2] : tk[3];
+    const uint64_t sc = c == 0 ? s0 : c == 1 ? s1 : c == 2 ? s2 : s3;
+    const uint64_t l2c = c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3];
+    uint64_t other = xb + (xa <= ix.primary && xa + size - 1 >= ix.primary);
+    other += (c < 3 ? s3 : 0) + (c < 2 ? s2 : 0) + (c < 1 ? s1 : 0);
+    const uint64_t na = l2c + 1 + tkc;
+    o0 = is_back ? na : other;
+    o1 = is_back ? other : na;
+    osz = sc;
+}
+
+// SMEM candidates of the search in progress, one private stack per lane: {x0:37, size:37, end:17} in 12 bytes.  The x1
+// side of an interval is not kept: the backward phase of bwt_smem1 never reads it, and neither does anything after
+// seeding (mem_collect_intv and mem_chain use x0, size and info only).  The first K entries of every lane sit in LDS as
+// three [K][64] word planes; deeper entries (reads with many distinct interval sizes: repeats, long reads) spill to a
+// lane-interleaved global area.  Limits checked on the host: text < 2^37 symbols, reads < 2^17 bases.
+struct CandStack {
+    uint32_t *v0, *v1, *v2;     // LDS planes, already offset by the lane
+    uint4* spill;               // [spill_cap][64], already offset by the lane
+    int K, spill_cap;
+    __device__ bool put(int e, uint64_t x0, uint64_t size, int end) {
+        const uint32_t w2 = (uint32_t)(x0 >> 32) | (uint32_t)(size >> 32) << 5 | (uint32_t)end << 10;
+        if (e < K) { v0[e * 64] = (uint32_t)x0; v1[e * 64] = (uint32_t)size; v2[e * 64] = w2; return true; }
+        if (e - K >= spill_cap) return false;
+        uint4 t; t.x = (uint32_t)x0; t.y = (uint32_t)size; t.z = w2; t.w = 0;
+        spill[(size_t)(e - K) * 64] = t;
+        return true;
+    }
+    __device__ void get(int e, uint64_t& x0, uint64_t& size, int& end) const {
+        uint32_t a, b, w2;
+        if (e < K) { a = v0[e * 64]; b = v1[e * 64]; w2 = v2[e * 64]; }
+        else { const uint4 t = spill[(size_t)(e - K) * 64]; a = t.x; b = t.y; w2 = t.z; }
+        x0 = (uint64_t)(w2 & 31) << 32 | a; size = (uint64_t)(w2 >> 5 & 31) << 32 | b; end = (int)(w2 >> 10);
+    }
 };
-
-// prev / curr candidates of one SMEM search: 16-byte packed entries (x0, x1, size: 37 bits each; end: 17 bits), so a
-// push or a read is one 16-byte lane request.  Limits (checked on the host): text < 2^37 symbols, reads < 2^17 bases.
-struct PackedVec {
-    uint4* a; int n; int cap; int stride;
-    static __device__ uint4 pack(const Intv& v) {
-        uint64_t lo = v.x0 | (v.x1 << 37), hi = (v.x1 >> 27) | (v.size << 10) | ((v.info & 0x1ffff) << 47);
-        uint4 r; r.x = (uint32_t)lo; r.y = (uint32_t)(lo >> 32); r.z = (uint32_t)hi; r.w = (uint32_t)(hi >> 32);
-        return r;
-    }
-    static __device__ Intv unpack(const uint4& r) {
-        uint64_t lo = (uint64_t)r.y << 32 | r.x, hi = (uint64_t)r.w << 32 | r.z;
-        Intv v; v.x0 = lo & 0x1fffffffffull; v.x1 = (lo >> 37) | ((hi & 0x3ff) << 27); v.size = (hi >> 10) & 0x1fffffffffull; v.info = hi >> 47;
-        return v;
-    }
-    __device__ Intv get(int i) const { return unpack(a[(size_t)i * stride]); }
-    __device__ uint4 raw(int i) const { return a[(size_t)i * stride]; }
-    __device__ void set_raw(int i, const uint4& v) { a[(size_t)i * stride] = v; }
-    __device__ bool push(const Intv& v) { if (n >= cap) return false; a[(size_t)n * stride] = pack(v); ++n; return true; }
-};
-
-DEV void pvec_reverse(PackedVec& v)
-{
-    for (int i = 0, j = v.n - 1; i < j; ++i, --j) { uint4 t = v.raw(i); v.set_raw(i, v.raw(j)); v.set_raw(j, t); }
-}
-
-DEV void vec_reverse(IntvVec& v, int from = 0)
-{
-    for (int i = from, j = v.n - 1; i < j; ++i, --j) { Intv t = v.get(i); v.set(i, v.get(j)); v.set(j, t); }
-}
-
-// all SMEMs through position x with interval size >= min_intv, appended to mem when at least min_seed_len long
-// (the caller's filter, fused so no intermediate vector is needed); returns the next x.
-// Forward-extend recording each size change, then backward-extend every candidate in lock-step,
-// longest first (App. B "SMEM(x, min_intv)").
-DEV int smem1(const DevIndex& ix, int len, const uint8_t* q, int x, int min_intv, int min_seed_len,
-              IntvVec& mem, PackedVec& v0, PackedVec& v1, uint32_t& n_ext, bool& ovf)
-{
-    Intv ik, ok;
-    PackedVec *prev = &v0, *curr = &v1, *swap;
-    int i, j, c;
-    const int mem0 = mem.n;
-    uint64_t last_start = ~0ull;                 // start of the most recently emitted match (before the length filter)
-    bool any = false;
-    if (q[x] > 3) return x + 1;
-    if (min_intv < 1) min_intv = 1;
-    set_intv(ix, q[x], ik);
-    ik.info = (uint64_t)(x + 1);
-    for (i = x + 1, curr->n = 0; i < len; ++i) {
-        if (q[i] < 4) {
-            c = 3 - q[i];
-            ok = extend_one(ix, ik, c, 0); ++n_ext;
-            if (ok.size != ik.size) {
-                if (!curr->push(ik)) { ovf = true; return len; }
-                if (ok.size < (uint64_t)min_intv) break;
-            }
-            ik = ok; ik.info = (uint64_t)(i + 1);
-        } else {
-            if (!curr->push(ik)) { ovf = true; return len; }
-            break;
-        }
-    }
-    if (i == len) { if (!curr->push(ik)) { ovf = true; return len; } }
-    pvec_reverse(*curr);
-    int ret = (int)curr->get(0).info;
-    swap = curr; curr = prev; prev = swap;
-    for (i = x - 1; i >= -1; --i) {
-        c = i < 0 ? -1 : q[i] < 4 ? q[i] : -1;
-        for (j = 0, curr->n = 0; j < prev->n; ++j) {
-            Intv p = prev->get(j);
-            if (c >= 0) { ok = extend_one(ix, p, c, 1); ++n_ext; }
-            if (c < 0 || ok.size < (uint64_t)min_intv) {
-                if (curr->n == 0) {
-                    if (!any || (uint64_t)(i + 1) < last_start) {
-                        any = true; last_start = (uint64_t)(i + 1);
-                        ik = p; ik.info |= (uint64_t)(i + 1) << 32;
-                        if ((int)((uint32_t)ik.info - (uint32_t)(ik.info >> 32)) >= min_seed_len) { if (!mem.push(ik)) { ovf = true; return len; } }
-                    }
-                }
-            } else if (curr->n == 0 || ok.size != curr->get(curr->n - 1).size) {
-                ok.info = p.info;
-                if (!curr->push(ok)) { ovf = true; return len; }
-            }
-        }
-        if (curr->n == 0) break;
-        swap = curr; curr = prev; prev = swap;
-    }
-    vec_reverse(mem, mem0);                       // this call's matches in order of start
-    return ret;
-}
-
-// pass 3: greedy forward seed (row a5)
-DEV int seed_strategy1(const DevIndex& ix, int len, const uint8_t* q, int x, int min_len, int max_intv, Intv& mem, uint32_t& n_ext)
-{
-    Intv ik, ok;
-    mem.x0 = mem.x1 = mem.size = mem.info = 0;
-    if (q[x] > 3) return x + 1;
-    set_intv(ix, q[x], ik);
-    for (int i = x + 1; i < len; ++i) {
-        if (q[i] < 4) {
-            int c = 3 - q[i];
-            ok = extend_one(ix, ik, c, 0); ++n_ext;
-            if (ok.size < (uint64_t)(int64_t)max_intv && i - x >= min_len) {
-                mem = ok;
-                mem.info = (uint64_t)x << 32 | (uint32_t)(i + 1);
-                return i + 1;
-            }
-            ik = ok;
-        } else return i + 1;
-    }
-    return len;
-}
 
 // ASCII -> 0..4 in place (upstream nst_nt4_table; bytes < 4 are kept as they are)
 __global__ void k_encode(uint8_t* seq, int64_t n_bytes)
@@ -145,95 +94,224 @@ __global__ void k_encode(uint8_t* seq, int64_t n_bytes)
     }
 }
 
-// mem_collect_intv (row a6) + the per-read bookkeeping mem_chain does before looking up the SA:
-// l_rep (repetitive fraction numerator) and the number of occurrences each interval contributes.
-// LDSQ: the 64 reads of the block are staged in LDS with one coalesced copy, so the per-step base look-ups of the
-// search do not compete with the occ gathers for vector-memory requests (used when 64 reads fit 24 KB).
+// mem_collect_intv (row a6): the three seeding passes of every read, written as a per-lane state machine fed from a
+// work queue.
+//
+// Upstream's control flow is four nested data-dependent loops per read.  Run one read per lane with that nesting, the
+// lanes of a wave sit in different loops most of the time and the wave issues each lane's gathers almost serially
+// (measured: ~10 k wave-level extension steps for ~860 extensions per read).  Here every iteration of ONE wave-level
+// loop performs at most one interval extension per lane -- the expensive part: four 16-byte gathers from two random
+// 32-byte occ blocks -- through a single call site shared by forward, backward and greedy extension, and all
+// bookkeeping between two extensions is register/LDS-only state transitions (no loops, no global round trips: the
+// candidate list is compacted in place instead of reversed and swapped).  A lane that finishes its read takes the next
+// one from the tile's queue, so lanes stay busy until the tile runs dry and a few resident waves per CU keep the
+// memory system saturated.  The sequence of extensions and candidate decisions of each read is exactly upstream's
+// (bwt_smem1 / bwt_seed_strategy1 / mem_collect_intv); only the order of equal-priority list entries before the final
+// sort differs, which the sort removes.
+enum { S_IDLE = 0, S_NEXT = 1, S_FWD = 2, S_BWD = 3, S_P3 = 4 };
+#define SEED_REFILL_MIN 4
+
 template <bool LDSQ>
-__global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView tv)
+__global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView tv, int K)
 {
-    HIP_DYNAMIC_SHARED(uint8_t, sq)
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    HIP_DYNAMIC_SHARED(uint32_t, lds)
+    const int lane = threadIdx.x;
+    CandStack V;
+    V.v0 = lds + lane; V.v1 = V.v0 + K * 64; V.v2 = V.v1 + K * 64; V.K = K;
+    V.spill = (uint4*)tv.smem_scratch + (size_t)blockIdx.x * tv.smem_cap * 64 + lane; V.spill_cap = tv.smem_cap;
+    uint8_t* sq = (uint8_t*)(lds + 3 * K * 64);          // [64 lanes][qs] base codes of the lanes' current reads
+    const int qs = tv.max_len + 1;
+    unsigned int* work = (unsigned int*)(tv.err + 8);    // next unclaimed read of the tile
+    const int min_seed_len = opt.min_seed_len;
+    const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
+    const uint64_t max_intv3 = (uint64_t)(int64_t)(int)opt.max_mem_intv;
+
+    int st = S_IDLE, r = 0, len = 0, pass = 1, x = 0, sx = 0, i = 0, k2 = 0, old_n = 0, mem_n = 0;
+    int nf = 0, lo = 0, rd = 0, wr = 0, c = -1, ret = 0, end = 0;
+    uint64_t min_intv = 1, last_start = 0, last_sz = 0, ik0 = 0, ik1 = 0, iks = 0;
+    bool any = false, ovf = false, exhausted = false;
+    const uint8_t* qg = tv.seq;
+    Intv* mem = tv.intv;
     uint32_t n_ext = 0;
-    int64_t base_off = 0;
-    if (LDSQ) {
-        const int r0 = blockIdx.x * blockDim.x;
-        const int r1 = r0 + 64 < tv.n_reads ? r0 + 64 : tv.n_reads;
-        base_off = tv.seq_off[r0];
-        const int nbytes = (int)(tv.seq_off[r1] - base_off);
-        for (int k = threadIdx.x; k < nbytes; k += 64) sq[k] = tv.seq[base_off + k];
-        __syncthreads();
-    }
-    if (r < tv.n_reads) {
-        const uint8_t* q = LDSQ ? (const uint8_t*)sq + (tv.seq_off[r] - base_off) : tv.seq + tv.seq_off[r];
-        int len = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
-        // scratch of wave-group g = r/64: [2 vectors][smem_cap entries][64 lanes]
-        uint4* sc = (uint4*)tv.smem_scratch + ((size_t)(r >> 6) * 2 * tv.smem_cap) * 64 + (r & 63);
-        PackedVec v0 = { sc, 0, tv.smem_cap, 64 };
-        PackedVec v1 = { sc + (size_t)tv.smem_cap * 64, 0, tv.smem_cap, 64 };
-        IntvVec mem = { tv.intv + (size_t)r * tv.intv_cap, 0, tv.intv_cap, 1 };
-        bool ovf = false;
-        int n_seeds = 0, l_rep = 0;
-        if (len >= opt.min_seed_len) {
-            int x = 0;
-            int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
-            while (x < len && !ovf) {                       // pass 1: all SMEMs
-                if (q[x] < 4) x = smem1(ix, len, q, x, 1, opt.min_seed_len, mem, v0, v1, n_ext, ovf);
-                else ++x;
-            }
-            int old_n = mem.n;
-            for (int k = 0; k < old_n && !ovf; ++k) {       // pass 2: re-seed long, rare SMEMs
-                Intv p = mem.get(k);
-                int start = (int)(p.info >> 32), end = (int)(int32_t)p.info;
-                if (end - start < split_len || p.size > (uint64_t)(int64_t)opt.split_width) continue;
-                smem1(ix, len, q, (start + end) >> 1, (int)(p.size + 1), opt.min_seed_len, mem, v0, v1, n_ext, ovf);
-            }
-            if (opt.max_mem_intv > 0) {                     // pass 3: greedy forward seeds
-                x = 0;
-                while (x < len && !ovf) {
-                    if (q[x] < 4) {
-                        Intv m;
-                        x = seed_strategy1(ix, len, q, x, opt.min_seed_len, (int)opt.max_mem_intv, m, n_ext);
-                        if (m.size > 0) { if (!mem.push(m)) ovf = true; }
-                    } else ++x;
+
+#define QAT(p) (LDSQ ? (int)sq[lane * qs + (p)] : (int)qg[(p)])
+#define FINISH() do { tv.n_intv[r] = ovf ? 0 : mem_n; if (ovf) atomicOr(tv.err, ERR_INTV_CAP); st = S_IDLE; } while (0)
+#define MEM_PUSH(X0, SZ, INFO) do { if (mem_n >= tv.intv_cap) ovf = true; else { Intv v_; v_.x0 = (X0); v_.x1 = 0; v_.size = (SZ); v_.info = (INFO); mem[mem_n++] = v_; } } while (0)
+#define PUSH_IK() do { if (V.put(nf, ik0, iks, end)) ++nf; else ovf = true; } while (0)
+#define BEGIN_BWD() do { ret = end; lo = 0; rd = wr = nf - 1; i = sx - 1; c = i >= 0 ? QAT(i) : 4; c = c < 4 ? c : -1; st = S_BWD; } while (0)
+
+    for (;;) {
+        // ---- work queue: idle lanes claim the next reads of the tile, the wave stages them in LDS together
+        const unsigned long long idle = __ballot(st == S_IDLE);
+        if (idle != 0ull && !exhausted && (__popcll(idle) >= SEED_REFILL_MIN || idle == ~0ull)) {
+            const int n_need = __popcll(idle);
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(work, (unsigned int)n_need);
+            base = (unsigned int)__shfl((int)base, 0);
+            if (base + (unsigned int)n_need >= (unsigned int)tv.n_reads) exhausted = true;
+            bool fresh = false;
+            if (st == S_IDLE) {
+                const unsigned int cand = base + (unsigned int)__popcll(idle & ((1ull << lane) - 1ull));
+                if (cand < (unsigned int)tv.n_reads) {
+                    r = (int)cand; fresh = true;
+                    const int64_t off = tv.seq_off[r];
+                    len = (int)(tv.seq_off[r + 1] - off - 1);
+                    qg = tv.seq + off;
+                    mem = tv.intv + (size_t)r * tv.intv_cap;
+                    mem_n = 0; ovf = false; pass = 1; x = 0; st = S_NEXT;
                 }
             }
-            if (!ovf) {
-                // sort by info.  Intervals with equal info are the same substring, hence identical records, so the
-                // order upstream's unstable sort leaves them in is unobservable: a plain insertion sort suffices.
-                for (int i = 1; i < mem.n; ++i) {
-                    Intv t = mem.a[i];
-                    int j = i;
-                    while (j > 0 && mem.a[j - 1].info > t.info) { mem.a[j] = mem.a[j - 1]; --j; }
-                    mem.a[j] = t;
+            if (LDSQ) {
+                unsigned long long got = __ballot(fresh);
+                while (got) {
+                    const int l = __ffsll((long long)got) - 1;
+                    got &= got - 1ull;
+                    const int rr = __shfl(r, l);
+                    const int64_t off = tv.seq_off[rr];
+                    const int nb = (int)(tv.seq_off[rr + 1] - off);
+                    for (int k = lane; k < nb; k += 64) sq[l * qs + k] = tv.seq[off + k];
                 }
-                int b = 0, e = 0;
-                int32_t* iso = tv.intv_seed_off + (size_t)r * tv.intv_cap;
-                for (int i = 0; i < mem.n; ++i) {
-                    Intv p = mem.a[i];
-                    int sb = (int)(p.info >> 32), se = (int)(uint32_t)p.info;
-                    iso[i] = n_seeds;
-                    {
-                        int64_t step = p.size > (uint64_t)(int64_t)opt.max_occ ? (int64_t)(p.size / (uint64_t)opt.max_occ) : 1;
-                        int64_t c = ((int64_t)p.size + step - 1) / step;
-                        n_seeds += (int)(c < opt.max_occ ? c : opt.max_occ);
+                __syncthreads();
+            }
+            if (fresh && len < min_seed_len) FINISH();
+        }
+        if (__ballot(st != S_IDLE) == 0ull) break;
+
+        // ---- between two searches: next SMEM start (pass 1), next interval to re-seed (pass 2), next greedy seed (pass 3)
+        if (st == S_NEXT) {
+            int nx = -1;
+            uint64_t nmin = 1;
+            if (pass == 1) {
+                if (x >= len) { pass = 2; old_n = mem_n; k2 = 0; }
+                else if (QAT(x) > 3) ++x;
+                else nx = x;
+            } else if (pass == 2) {
+                if (k2 >= old_n) { pass = 3; x = 0; if (!(opt.max_mem_intv > 0)) FINISH(); }
+                else {
+                    const uint64_t psz = mem[k2].size, pinfo = mem[k2].info;
+                    const int s0 = (int)(pinfo >> 32), e0 = (int)(int32_t)pinfo;
+                    if (e0 - s0 < split_len || psz > (uint64_t)(int64_t)opt.split_width) ++k2;
+                    else {
+                        const int m = (s0 + e0) >> 1;
+                        if (QAT(m) > 3) ++k2;                       // bwt_smem1 returns at once on an ambiguous base
+                        else { nx = m; nmin = psz + 1; }
                     }
-                    if (p.size <= (uint64_t)(int64_t)opt.max_occ) continue;
-                    if (sb > e) { l_rep += e - b; b = sb; e = se; }
-                    else e = e > se ? e : se;
                 }
-                l_rep += e - b;
+            } else {
+                if (x >= len) FINISH();
+                else if (QAT(x) > 3) ++x;
+                else {
+                    const int b = QAT(x);
+                    ik0 = ix.L2[b] + 1; iks = ix.L2[b + 1] - ix.L2[b]; ik1 = ix.L2[3 - b] + 1;
+                    sx = x; i = x + 1; st = S_P3;
+                }
+            }
+            if (nx >= 0) {                                          // enter bwt_smem1(nx, nmin)
+                const int b = QAT(nx);
+                ik0 = ix.L2[b] + 1; iks = ix.L2[b + 1] - ix.L2[b]; ik1 = ix.L2[3 - b] + 1;
+                sx = nx; min_intv = nmin; end = sx + 1; i = sx + 1; nf = 0; any = false; st = S_FWD;
             }
         }
-        if (ovf) { atomicOr(tv.err, ERR_INTV_CAP); mem.n = 0; n_seeds = 0; l_rep = 0; }
-        tv.n_intv[r] = mem.n;
-        tv.n_seeds[r] = n_seeds;
-        tv.l_rep[r] = l_rep;
+
+        // ---- what this lane extends in this iteration
+        bool need = false, bw = false, back = false;
+        int rc = 0, pend = 0;
+        uint64_t r0 = 0, r1 = 0, rs = 0;
+        if (st == S_FWD || st == S_P3) {
+            const int cq = i < len ? QAT(i) : 4;
+            if (cq < 4) { need = true; rc = 3 - cq; r0 = ik0; r1 = ik1; rs = iks; }
+            else if (st == S_FWD) {                                 // end of the read or an ambiguous base: forward phase over
+                PUSH_IK();
+                if (ovf) FINISH(); else BEGIN_BWD();
+            } else { x = i < len ? i + 1 : len; st = S_NEXT; }      // bwt_seed_strategy1 found nothing from sx
+        }
+        if (st == S_BWD) {
+            V.get(rd, r0, rs, pend);
+            bw = true;
+            if (c >= 0) { need = true; back = true; rc = c; }
+        }
+
+        // ---- one interval extension per lane, issued by the whole wave together
+        uint64_t o0 = 0, o1 = 0, os = 0;
+        if (need) { extend_sm(ix, r0, r1, rs, rc, back, o0, o1, os); ++n_ext; }
+
+        // ---- consume the result
+        if (bw) {                                                   // backward phase: candidate rd of the row for position i
+            if (!need || os < min_intv) {                           // cannot be extended to i: a match starts at i + 1
+                if (wr == nf - 1 && (!any || (uint64_t)(i + 1) < last_start)) {
+                    any = true; last_start = (uint64_t)(i + 1);
+                    if (pend - (i + 1) >= min_seed_len) MEM_PUSH(r0, rs, (uint64_t)(i + 1) << 32 | (uint32_t)pend);
+                }
+            } else if (wr == nf - 1 || os != last_sz) {             // survivor; rows are compacted in place, longest on top
+                V.put(wr, o0, os, pend); --wr; last_sz = os;
+            }
+            --rd;
+            if (rd < lo) {                                          // row complete
+                if (wr == nf - 1) { if (pass == 1) x = ret; else ++k2; st = S_NEXT; }
+                else { lo = wr + 1; rd = wr = nf - 1; --i; c = i >= 0 ? QAT(i) : 4; c = c < 4 ? c : -1; }
+            }
+            if (ovf) FINISH();
+        } else if (need) {
+            if (st == S_FWD) {
+                bool stop = false;
+                if (os != iks) { PUSH_IK(); stop = os < min_intv; }
+                if (ovf) FINISH();
+                else if (stop) BEGIN_BWD();
+                else { ik0 = o0; ik1 = o1; iks = os; end = i + 1; ++i; }
+            } else {                                                // S_P3
+                if (os < max_intv3 && i - sx >= min_seed_len) {
+                    if (os > 0) MEM_PUSH(o0, os, (uint64_t)sx << 32 | (uint32_t)(i + 1));
+                    x = i + 1; st = S_NEXT;
+                    if (ovf) FINISH();
+                } else { ik0 = o0; ik1 = o1; iks = os; ++i; }
+            }
+        }
     }
+#undef QAT
+#undef FINISH
+#undef MEM_PUSH
+#undef PUSH_IK
+#undef BEGIN_BWD
     // one counter atomic per wave
     unsigned long long tot = n_ext;
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o);
-    if ((threadIdx.x & 63) == 0) { count_add(&tv.cnt->n_ext, tot); }
+    if (lane == 0) { count_add(&tv.cnt->n_ext, tot); }
+}
+
+// the per-read bookkeeping between mem_collect_intv and the SA look-ups of mem_chain: intervals in upstream's order
+// (sorted by info), the number of occurrences each contributes, and l_rep (repetitive fraction numerator)
+__global__ void k_seed_fin(MemOpt opt, TileView tv)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= tv.n_reads) return;
+    Intv* a = tv.intv + (size_t)r * tv.intv_cap;
+    const int n = tv.n_intv[r];
+    // Intervals with equal info are the same substring, hence identical records, so the order upstream's unstable
+    // sort leaves them in is unobservable: a plain insertion sort suffices.
+    for (int i = 1; i < n; ++i) {
+        Intv t = a[i];
+        int j = i;
+        while (j > 0 && a[j - 1].info > t.info) { a[j] = a[j - 1]; --j; }
+        a[j] = t;
+    }
+    int n_seeds = 0, l_rep = 0, b = 0, e = 0;
+    int32_t* iso = tv.intv_seed_off + (size_t)r * tv.intv_cap;
+    for (int i = 0; i < n; ++i) {
+        const Intv p = a[i];
+        const int sb = (int)(p.info >> 32), se = (int)(uint32_t)p.info;
+        iso[i] = n_seeds;
+        {
+            int64_t step = p.size > (uint64_t)(int64_t)opt.max_occ ? (int64_t)(p.size / (uint64_t)opt.max_occ) : 1;
+            int64_t c = ((int64_t)p.size + step - 1) / step;
+            n_seeds += (int)(c < opt.max_occ ? c : opt.max_occ);
+        }
+        if (p.size <= (uint64_t)(int64_t)opt.max_occ) continue;
+        if (sb > e) { l_rep += e - b; b = sb; e = se; }
+        else e = e > se ? e : se;
+    }
+    l_rep += e - b;
+    tv.n_seeds[r] = n_seeds;
+    tv.l_rep[r] = l_rep;
 }
 
 // exclusive scan int32 -> int64 (single workgroup; n is a tile's read count, so this is tiny)
@@ -324,12 +402,25 @@ void launch_encode(hipStream_t st, uint8_t* seq, int64_t n_bytes)
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(k_encode, dim3((unsigned)nb), dim3(256), 0, st, seq, n_bytes);
 }
+// k_seed is a persistent grid: as many one-wave workgroups as fit the CUs' LDS (the candidate stacks dominate), each
+// pulling reads from the tile's queue (tv.err[8], zeroed by the caller with the other flags).
 void launch_seed(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv)
 {
     if (tv.n_reads <= 0) return;
-    const size_t lds = (size_t)64 * ((size_t)tv.max_len + 1) + 64;
-    if (lds <= 24576) hipLaunchKernelGGL(k_seed<true>, dim3((tv.n_reads + 63) / 64), dim3(64), lds, st, ix, opt, tv);
-    else hipLaunchKernelGGL(k_seed<false>, dim3((tv.n_reads + 63) / 64), dim3(64), 0, st, ix, opt, tv);
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
+    int K = 32, wpc = 0;
+    { const char* e = getenv("BWAMEM_HIP_SEED_K"); if (e && atoi(e) > 0) K = atoi(e); }
+    { const char* e = getenv("BWAMEM_HIP_SEED_WPC"); if (e && atoi(e) > 0) wpc = atoi(e); }
+    const size_t qbytes = (size_t)64 * ((size_t)tv.max_len + 1);
+    const bool ldsq = qbytes <= 24576;
+    const size_t lds = (size_t)3 * K * 64 * 4 + (ldsq ? qbytes : 0) + 16;
+    if (!wpc) { wpc = (int)((size_t)(160 * 1024) / ((lds + 1023) & ~(size_t)1023)); wpc = wpc < 1 ? 1 : wpc > 16 ? 16 : wpc; }
+    const int groups = (tv.n_reads + 63) / 64;
+    const int grid = groups < n_cu * wpc ? groups : n_cu * wpc;
+    if (ldsq) hipLaunchKernelGGL(k_seed<true>, dim3(grid), dim3(64), lds, st, ix, opt, tv, K);
+    else hipLaunchKernelGGL(k_seed<false>, dim3(grid), dim3(64), lds, st, ix, opt, tv, K);
+    hipLaunchKernelGGL(k_seed_fin, dim3((tv.n_reads + 255) / 256), dim3(256), 0, st, opt, tv);
 }
 void launch_scan(hipStream_t st, const int32_t* in, int64_t* out, int n)
 {

@@ -36,16 +36,18 @@ static __device__ inline bool wave_any(int pred) { return __ballot(pred) != 0ull
 #define DPP_ROW_BCAST15 0x142
 #define DPP_ROW_BCAST31 0x143
 
-// inclusive prefix maximum over the 64 lanes; lanes without a source keep their own value (identity = neg)
-static __device__ inline int dpp_prefix_max(int v, int neg)
+// inclusive prefix maximum over the 64 lanes.  Lanes without a source keep their own value: the DPP "old" operand is
+// INT_MIN, the identity of v_max_i32, which lets the compiler fold each move into the max (one v_max_i32_dpp per step).
+static __device__ inline int dpp_prefix_max(int v, int /*neg*/)
 {
+    const int id = (int)0x80000000;
     int t;
-    t = __builtin_amdgcn_update_dpp(neg, v, DPP_ROW_SHR(1), 0xf, 0xf, false); v = v > t ? v : t;
-    t = __builtin_amdgcn_update_dpp(neg, v, DPP_ROW_SHR(2), 0xf, 0xf, false); v = v > t ? v : t;
-    t = __builtin_amdgcn_update_dpp(neg, v, DPP_ROW_SHR(4), 0xf, 0xf, false); v = v > t ? v : t;
-    t = __builtin_amdgcn_update_dpp(neg, v, DPP_ROW_SHR(8), 0xf, 0xf, false); v = v > t ? v : t;
-    t = __builtin_amdgcn_update_dpp(neg, v, DPP_ROW_BCAST15, 0xa, 0xf, false); v = v > t ? v : t;
-    t = __builtin_amdgcn_update_dpp(neg, v, DPP_ROW_BCAST31, 0xc, 0xf, false); v = v > t ? v : t;
+    t = __builtin_amdgcn_update_dpp(id, v, DPP_ROW_SHR(1), 0xf, 0xf, false); v = v > t ? v : t;
+    t = __builtin_amdgcn_update_dpp(id, v, DPP_ROW_SHR(2), 0xf, 0xf, false); v = v > t ? v : t;
+    t = __builtin_amdgcn_update_dpp(id, v, DPP_ROW_SHR(4), 0xf, 0xf, false); v = v > t ? v : t;
+    t = __builtin_amdgcn_update_dpp(id, v, DPP_ROW_SHR(8), 0xf, 0xf, false); v = v > t ? v : t;
+    t = __builtin_amdgcn_update_dpp(id, v, DPP_ROW_BCAST15, 0xa, 0xf, false); v = v > t ? v : t;
+    t = __builtin_amdgcn_update_dpp(id, v, DPP_ROW_BCAST31, 0xc, 0xf, false); v = v > t ? v : t;
     return v;
 }
 // lane l <- lane l-1; lane 0 <- fill

@@ -71,3 +71,14 @@ def test_emu_long_reads_seed_rescoring(emu, oracle, small_genome):
     seqs, img = small_genome
     reads = B.simulate_reads(seqs, 2, length=800, seed=5, sub=0.06, indel=0.02)
     _cmp(emu, oracle, img, reads)
+
+
+def test_emu_seed_work_queue_and_spill(emu, oracle, small_genome, monkeypatch):
+    """k_seed: one resident wave pulling 150 reads from the tile queue (lanes refill as they finish), candidate stacks
+    of 3 LDS entries so nearly every search spills to the global area"""
+    seqs, img = small_genome
+    reads = B.simulate_reads(seqs, 130, length=70, seed=21, sub=0.03, indel=0.004, n_rate=0.01, random_frac=0.1)
+    reads += [b"ACGT" * 20, b"N" * 30, b"", b"A" * 18, b"ACGTN" * 20] * 4
+    monkeypatch.setenv("BWAMEM_HIP_SEED_WPC", "1")
+    monkeypatch.setenv("BWAMEM_HIP_SEED_K", "3")
+    _cmp(emu, oracle, img, reads)
