@@ -195,6 +195,31 @@ DEV uint64_t hash_64(uint64_t key)
     return key;
 }
 
+// Scoring-matrix access for the row loops of the DP kernels.  The matrix lives in the kernel argument block; indexing it
+// with run-time values makes the compiler issue byte loads through the vector memory path in every DP row.  Instead the
+// 25 entries are repacked once (wave-uniform, scalar registers) into one word per query base holding the scores against
+// target bases 0..3, plus the score against an ambiguous target base; a lane then keeps the word of its own query base
+// and a row costs one bit-field extract.
+struct ScoreTab { uint32_t p[5]; int n[5]; };
+DEV ScoreTab score_tab(const MemOpt& opt)
+{
+    ScoreTab T;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        T.p[q] = (uint32_t)(uint8_t)opt.mat[q] | (uint32_t)(uint8_t)opt.mat[5 + q] << 8 | (uint32_t)(uint8_t)opt.mat[10 + q] << 16 | (uint32_t)(uint8_t)opt.mat[15 + q] << 24;
+        T.n[q] = opt.mat[20 + q];
+    }
+    return T;
+}
+DEV void score_lane(const ScoreTab& T, int q, uint32_t& p, int& n)
+{
+    p = q == 0 ? T.p[0] : q == 1 ? T.p[1] : q == 2 ? T.p[2] : q == 3 ? T.p[3] : T.p[4];
+    n = q == 0 ? T.n[0] : q == 1 ? T.n[1] : q == 2 ? T.n[2] : q == 3 ? T.n[3] : T.n[4];
+}
+// score of the lane's query base against target base tb (0..4)
+DEV int score_at(uint32_t p, int n, int tb) { return tb < 4 ? (int)(int8_t)(p >> (tb << 3)) : n; }
+DEV int score_max(const MemOpt& opt) { int mx = 0; for (int k = 0; k < 25; ++k) mx = mx > opt.mat[k] ? mx : opt.mat[k]; return mx; }
+
 DEV int cal_max_gap(const MemOpt& opt, int qlen)
 {
     int l_del = (int)((double)(qlen * opt.a - opt.o_del) / opt.e_del + 1.);

@@ -17,6 +17,30 @@
 
 struct GLds { int32_t* eh_h; int32_t* eh_e; int32_t* tmpM; };
 
+// backtrack through the direction bytes (lane 0); ops come out end-to-start and are reversed in place
+static __device__ int traceback(const uint8_t* z, int n_col, int w, int tlen, int qlen, int lane, uint32_t* cigar, int cig_cap, int& err)
+{
+    int n = 0;
+    if (lane == 0) {
+        int which = 0, i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+        bool ovf = false;
+        while (i >= 0 && k >= 0 && !ovf) {
+            int op;
+            which = z[(int64_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+            if (which == 0) { op = 0; --i; --k; }
+            else if (which == 1) { op = 2; --i; }
+            else { op = 1; --k; }
+            if (n == 0 || op != (int)(cigar[n - 1] & 0xf)) { if (n >= cig_cap) ovf = true; else cigar[n++] = 1u << 4 | (uint32_t)op; }
+            else cigar[n - 1] += 1u << 4;
+        }
+        if (!ovf && i >= 0) { if (n == 0 || 2 != (int)(cigar[n - 1] & 0xf)) { if (n >= cig_cap) ovf = true; else cigar[n++] = (uint32_t)(i + 1) << 4 | 2; } else cigar[n - 1] += (uint32_t)(i + 1) << 4; }
+        if (!ovf && k >= 0) { if (n == 0 || 1 != (int)(cigar[n - 1] & 0xf)) { if (n >= cig_cap) ovf = true; else cigar[n++] = (uint32_t)(k + 1) << 4 | 1; } else cigar[n - 1] += (uint32_t)(k + 1) << 4; }
+        for (int a = 0; a < n >> 1; ++a) { uint32_t tmp = cigar[a]; cigar[a] = cigar[n - 1 - a]; cigar[n - 1 - a] = tmp; }
+        if (ovf) { err |= ERR_CIGAR_CAP; n = 0; }
+    }
+    return wave_bcast(n, 0);
+}
+
 // one ksw_global2 call; the raw CIGAR (before clip / deletion squeezing) goes to cigar[0..*n_cigar)
 static __device__ int global_wave(const DevIndex& ix, const MemOpt& opt, const GLds& L, int lane, const SeqAcc& A, int w,
                                   uint8_t* z, int n_col, uint32_t* cigar, int cig_cap, int* n_cigar, int& err)
@@ -24,6 +48,7 @@ static __device__ int global_wave(const DevIndex& ix, const MemOpt& opt, const G
     const int qlen = A.qlen, tlen = A.tlen;
     const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const ScoreTab ST = score_tab(opt);
     for (int j = lane; j <= qlen; j += WAVE) {
         L.eh_h[j] = j == 0 ? 0 : (j <= w ? -(o_ins + e_ins * j) : MINUS_INF);
         L.eh_e[j] = MINUS_INF;
@@ -33,7 +58,7 @@ static __device__ int global_wave(const DevIndex& ix, const MemOpt& opt, const G
     for (int i = 0; i < tlen; ++i) {
         if ((i & 63) == 0) { int ii = i + lane; tch = ii < tlen ? acc_t(ix, A, ii) : 4; }
         const int tb = wave_bcast(tch, i & 63);
-        const int ms0 = opt.mat[tb * 5], ms1 = opt.mat[tb * 5 + 1], ms2 = opt.mat[tb * 5 + 2], ms3 = opt.mat[tb * 5 + 3], ms4 = opt.mat[tb * 5 + 4];
+        const int ms0 = score_at(ST.p[0], ST.n[0], tb), ms1 = score_at(ST.p[1], ST.n[1], tb), ms2 = score_at(ST.p[2], ST.n[2], tb), ms3 = score_at(ST.p[3], ST.n[3], tb), ms4 = score_at(ST.p[4], ST.n[4], tb);
         const int beg = i > w ? i - w : 0;
         const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
         const int h1i = beg == 0 ? -(o_del + e_del * (i + 1)) : MINUS_INF;
@@ -83,27 +108,64 @@ static __device__ int global_wave(const DevIndex& ix, const MemOpt& opt, const G
         __syncthreads();
     }
     const int score = L.eh_h[qlen];
-    int n = 0;
-    if (lane == 0) {                                                 // backtrack; ops come out end-to-start
-        int which = 0, i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
-        bool ovf = false;
-        while (i >= 0 && k >= 0 && !ovf) {
-            int op;
-            which = z[(int64_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
-            if (which == 0) { op = 0; --i; --k; }
-            else if (which == 1) { op = 2; --i; }
-            else { op = 1; --k; }
-            if (n == 0 || op != (int)(cigar[n - 1] & 0xf)) { if (n >= cig_cap) ovf = true; else cigar[n++] = 1u << 4 | (uint32_t)op; }
-            else cigar[n - 1] += 1u << 4;
-        }
-        if (!ovf && i >= 0) { if (n == 0 || 2 != (int)(cigar[n - 1] & 0xf)) { if (n >= cig_cap) ovf = true; else cigar[n++] = (uint32_t)(i + 1) << 4 | 2; } else cigar[n - 1] += (uint32_t)(i + 1) << 4; }
-        if (!ovf && k >= 0) { if (n == 0 || 1 != (int)(cigar[n - 1] & 0xf)) { if (n >= cig_cap) ovf = true; else cigar[n++] = (uint32_t)(k + 1) << 4 | 1; } else cigar[n - 1] += (uint32_t)(k + 1) << 4; }
-        for (int a = 0; a < n >> 1; ++a) { uint32_t tmp = cigar[a]; cigar[a] = cigar[n - 1 - a]; cigar[n - 1 - a] = tmp; }
-        if (ovf) { err |= ERR_CIGAR_CAP; n = 0; }
-    }
-    n = wave_bcast(n, 0);
-    *n_cigar = n;
+    *n_cigar = traceback(z, n_col, w, tlen, qlen, lane, cigar, cig_cap, err);
     __syncthreads();
+    return score;
+}
+
+// The same DP for bands of at most 64 columns (2w + 1 <= 64: every short-read job), with the band across the lanes:
+// lane l owns column j = i - w + l of row i, i.e. one diagonal.  H(i-1,j-1) is then the lane's own value of the previous
+// row, E(i,j) comes from the lane above (one DPP shift), F is the max-plus prefix over the lanes of the row (DPP scan),
+// and the query slides down the lanes one position per row.  Nothing of the DP state lives in LDS and no barrier is
+// needed; only the direction bytes are stored (z, in upstream's [row][column - beg] layout) for the traceback.
+static __device__ int global_wave_diag(const DevIndex& ix, const MemOpt& opt, const uint8_t* sq, int lane, const SeqAcc& A, int w,
+                                       uint8_t* z, int n_col, uint32_t* cigar, int cig_cap, int* n_cigar, int& err)
+{
+    const int qlen = A.qlen, tlen = A.tlen;
+    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const ScoreTab ST = score_tab(opt);
+    const int j0 = lane - w;
+    int hd = j0 == 0 ? 0 : (j0 > 0 && j0 <= w ? -(o_ins + e_ins * j0) : MINUS_INF);   // H(-1, j-1): upstream's initial eh[j].h
+    int e = MINUS_INF;
+    int qv = j0 >= 0 && j0 < qlen ? sq[j0] : 4;
+    int tch = 4, h = MINUS_INF;
+    for (int i = 0; i < tlen; ++i) {
+        if ((i & 63) == 0) { int ii = i + lane; tch = ii < tlen ? acc_t(ix, A, ii) : 4; }
+        const int tb = wave_readlane(tch, i & 63);
+        const int ms0 = score_at(ST.p[0], ST.n[0], tb), ms1 = score_at(ST.p[1], ST.n[1], tb), ms2 = score_at(ST.p[2], ST.n[2], tb), ms3 = score_at(ST.p[3], ST.n[3], tb), ms4 = score_at(ST.p[4], ST.n[4], tb);
+        const int inj = i + 64 - w;                                  // query position entering lane 63 for the next row
+        const int qin = inj >= 0 && inj < qlen ? sq[inj] : 4;
+        const int j = i - w + lane;
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        const int lb = beg - (i - w);                                // first lane of the band in this row
+        const bool act = j >= beg && j < end;
+        const int sc = qv == 0 ? ms0 : qv == 1 ? ms1 : qv == 2 ? ms2 : qv == 3 ? ms3 : ms4;
+        const int m = hd + sc;
+        const int tins = m - oe_ins;
+        const int U = act ? tins + lane * e_ins : NEG_SCAN;
+        const int P = dpp_prefix_max(U, NEG_SCAN);
+        const int Pex = dpp_shr1(P, NEG_SCAN);
+        int f = MINUS_INF - (lane - lb) * e_ins;
+        { const int g = Pex - (lane - 1) * e_ins; f = f > g ? f : g; }
+        int d = m >= e ? 0 : 1;
+        h = m >= e ? m : e;
+        d = h >= f ? d : 2;
+        h = h >= f ? h : f;
+        const int t = m - oe_del;
+        int e2 = e - e_del;
+        d |= e2 > t ? 1 << 2 : 0;
+        e2 = e2 > t ? e2 : t;
+        d |= (f - e_ins) > tins ? 2 << 4 : 0;
+        if (act) z[(int64_t)i * n_col + (lane - lb)] = (uint8_t)d;
+        // state of the next row: the lane moves one column to the right along its diagonal
+        hd = act ? h : (j == -1 ? -(o_del + e_del * (i + 1)) : MINUS_INF);
+        e = dpp_shl1(act ? e2 : MINUS_INF, MINUS_INF);
+        qv = dpp_shl1(qv, qin);
+    }
+    const int score = wave_bcast(h, qlen - 1 - (tlen - 1 - w));     // H(tlen-1, qlen-1); the caller checked that lane is in the band
+    *n_cigar = traceback(z, n_col, w, tlen, qlen, lane, cigar, cig_cap, err);
     return score;
 }
 
@@ -117,7 +179,8 @@ __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView
     const uint8_t* query = tv.seq + tv.seq_off[jb.read];
     const int cap = tv.max_len + 2;
     GLds L; L.eh_h = smem; L.eh_e = smem + cap; L.tmpM = smem + 2 * cap;
-    uint8_t* z_lds = (uint8_t*)(smem + 3 * cap);
+    uint8_t* sq = (uint8_t*)(smem + 3 * cap);                          // the region's query bases, in alignment order
+    uint8_t* z_lds = sq + ((cap + 15) & ~15);
     int err = 0;
     SeqAcc A; A.q = query + ar.qb; A.qlen = ar.qe - ar.qb; A.rev = ar.rb >= ix.l_pac; A.t0 = ar.rb; A.tlen = (int)(ar.re - ar.rb);
     uint32_t* cigar = cig_pool + (size_t)job * cig_cap;
@@ -126,6 +189,8 @@ __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView
     const int l_query = A.qlen, rlen = A.tlen;
     const bool usable = !(l_query <= 0 || ar.rb >= ar.re || (ar.rb < ix.l_pac && ar.re > ix.l_pac) || ar.re > ix.l_pac << 1 || ar.rb < 0);
     if (usable) {
+        for (int j = lane; j < l_query; j += WAVE) sq[j] = (uint8_t)acc_q(A, j);
+        __syncthreads();
         do {
             w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
             int w, max_gap, max_ins, max_del, min_w, d;                // band of bwa_gen_cigar2
@@ -148,7 +213,9 @@ __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView
                 if (at + need > zpool_cap) { err |= ERR_ZPOOL; break; }
                 z = zpool + at;
             }
-            score = global_wave(ix, opt, L, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err);
+            const int l_end = l_query - 1 - (rlen - 1 - w);            // lane of the final cell in the diagonal form
+            if (2 * w + 1 <= WAVE && l_end >= 0 && l_end <= 2 * w) score = global_wave_diag(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err);
+            else score = global_wave(ix, opt, L, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err);
             if (score == last_sc || w2 == opt.w << 2) break;
             last_sc = score;
             w2 <<= 1;
@@ -165,8 +232,9 @@ void launch_gcigar(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const 
                    uint8_t* zpool, unsigned long long zpool_cap, unsigned long long* zpool_cur)
 {
     if (n_jobs <= 0) return;
-    const int z_lds_cap = 16384;
+    int z_lds_cap = 6144;                                            // covers bands of ~40 columns x 150 rows; larger matrices go to the HBM pool
+    { const char* e = getenv("BWAMEM_HIP_ZLDS"); if (e && atoi(e) >= 0) z_lds_cap = atoi(e); }
     size_t cap = (size_t)tv.max_len + 2;
-    size_t shmem = 3 * cap * sizeof(int32_t) + (size_t)z_lds_cap + 64;
+    size_t shmem = 3 * cap * sizeof(int32_t) + ((cap + 15) & ~(size_t)15) + (size_t)z_lds_cap + 64;
     hipLaunchKernelGGL(k_gcigar, dim3(n_jobs), dim3(64), shmem, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap);
 }

@@ -27,6 +27,7 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     int i, beg, end, max, max_i, max_j, max_ins, max_del, max_ie, gscore, max_off;
     if (h0 < 0) h0 = 0;
+    const ScoreTab ST = score_tab(opt);
     // first row: decay from h0 by insertion costs
     for (int j = lane; j <= qlen; j += WAVE) {
         int v = 0;
@@ -38,8 +39,7 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
         L.eh_h[j] = v; L.eh_e[j] = 0;
     }
     {   // clip the band by the longest affordable gap
-        int mx = 0;
-        for (int k = 0; k < 25; ++k) mx = mx > opt.mat[k] ? mx : opt.mat[k];
+        const int mx = score_max(opt);
         max_ins = (int)((double)(qlen * mx + end_bonus - o_ins) / e_ins + 1.);
         max_ins = max_ins > 1 ? max_ins : 1;
         w = w < max_ins ? w : max_ins;
@@ -57,7 +57,7 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
             tch = ii < tlen ? ref_base2(ix, t0 + (int64_t)tstep * ii) : 4;
         }
         const int tb = wave_bcast(tch, i & 63);
-        const int ms0 = opt.mat[tb * 5], ms1 = opt.mat[tb * 5 + 1], ms2 = opt.mat[tb * 5 + 2], ms3 = opt.mat[tb * 5 + 3], ms4 = opt.mat[tb * 5 + 4];
+        const int ms0 = score_at(ST.p[0], ST.n[0], tb), ms1 = score_at(ST.p[1], ST.n[1], tb), ms2 = score_at(ST.p[2], ST.n[2], tb), ms3 = score_at(ST.p[3], ST.n[3], tb), ms4 = score_at(ST.p[4], ST.n[4], tb);
         int m = 0, mj = -1, h1, h1i, hlast = 0;
         if (beg < i - w) beg = i - w;
         if (end > i + w + 1) end = i + w + 1;
@@ -175,7 +175,9 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
     const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     int i, beg, end, max, max_i, max_j, max_ins, max_del, max_ie, gscore, max_off;
-    int ehh[C], ehe[C], qc[C];
+    int ehh[C], ehe[C], scn[C];
+    uint32_t scp[C];
+    const ScoreTab ST = score_tab(opt);
     if (h0 < 0) h0 = 0;
 #pragma unroll
     for (int t = 0; t < C; ++t) {                          // first row: decay from h0 by insertion costs
@@ -187,11 +189,10 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
             if (j == 1 || vj + e_ins > e_ins) v = vj;
         }
         ehh[t] = v; ehe[t] = 0;
-        qc[t] = j < qlen ? query[q0 + qstep * j] : 4;
+        score_lane(ST, j < qlen ? query[q0 + qstep * j] : 4, scp[t], scn[t]);
     }
     {
-        int mx = 0;
-        for (int k = 0; k < 25; ++k) mx = mx > opt.mat[k] ? mx : opt.mat[k];
+        const int mx = score_max(opt);
         max_ins = (int)((double)(qlen * mx + end_bonus - o_ins) / e_ins + 1.);
         max_ins = max_ins > 1 ? max_ins : 1;
         w = w < max_ins ? w : max_ins;
@@ -205,7 +206,6 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
     for (i = 0; i < tlen; ++i) {
         if ((i & 63) == 0) { int ii = i + lane; tch = ii < tlen ? ref_base2(ix, t0 + (int64_t)tstep * ii) : 4; }
         const int tb = wave_readlane(tch, i & 63);
-        const int ms0 = opt.mat[tb * 5], ms1 = opt.mat[tb * 5 + 1], ms2 = opt.mat[tb * 5 + 2], ms3 = opt.mat[tb * 5 + 3], ms4 = opt.mat[tb * 5 + 4];
         int m = 0, mj = -1, h1, h1i;
         if (beg < i - w) beg = i - w;
         if (end > i + w + 1) end = i + w + 1;
@@ -220,7 +220,7 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
             const int c0 = t * WAVE, j = c0 + lane;
             const bool act = j >= beg && j < end;
             const int Mp = ehh[t], e = ehe[t];
-            const int sc = qc[t] == 0 ? ms0 : qc[t] == 1 ? ms1 : qc[t] == 2 ? ms2 : qc[t] == 3 ? ms3 : ms4;
+            const int sc = score_at(scp[t], scn[t], tb);
             const int M = act && Mp ? Mp + sc : 0;
             int tt = M - oe_ins; tt = tt > 0 ? tt : 0;
             const int U = act ? tt + j * e_ins : NEG_INF_I32;
@@ -317,7 +317,12 @@ struct U64Lt { __device__ bool operator()(uint64_t a, uint64_t b) const { return
 
 #define MAX_BAND_TRY 2
 
-__global__ void __launch_bounds__(64) k_extend(DevIndex ix, MemOpt opt, TileView tv)
+// minimum resident waves per SIMD the register allocator must leave room for (the DP rows are one long dependent
+// chain per wave, so latency hiding comes from co-resident waves)
+#ifndef K_EXTEND_MIN_WAVES
+#define K_EXTEND_MIN_WAVES 4
+#endif
+__global__ void __launch_bounds__(64, K_EXTEND_MIN_WAVES) k_extend(DevIndex ix, MemOpt opt, TileView tv)
 {
     HIP_DYNAMIC_SHARED(int32_t, smem)
     const int r = blockIdx.x, lane = threadIdx.x;

@@ -56,25 +56,36 @@ DEV void extend_sm(const DevIndex& ix, uint64_t x0, uint64_t x1, uint64_t size, 
 
 // SMEM candidates of the search in progress, one private stack per lane: {x0:37, size:37, end:17} in 12 bytes.  The x1
 // side of an interval is not kept: the backward phase of bwt_smem1 never reads it, and neither does anything after
-// seeding (mem_collect_intv and mem_chain use x0, size and info only).  The first K entries of every lane sit in LDS as
-// three [K][64] word planes; deeper entries (reads with many distinct interval sizes: repeats, long reads) spill to a
-// lane-interleaved global area.  Limits checked on the host: text < 2^37 symbols, reads < 2^17 bases.
+// seeding (mem_collect_intv and mem_chain use x0, size and info only).  The top K entries of every lane's stack (K a
+// power of two) sit in LDS as three [K][64] word planes addressed as a ring; entries pushed out of the ring by deeper
+// stacks (many distinct interval sizes: repeats, long reads) live in a lane-interleaved global area.  The top is the
+// hot part: the backward phase keeps its survivors packed against the top of the stack.  Limits checked on the host:
+// text < 2^37 symbols, reads < 2^17 bases.
 struct CandStack {
     uint32_t *v0, *v1, *v2;     // LDS planes, already offset by the lane
     uint4* spill;               // [spill_cap][64], already offset by the lane
     int K, spill_cap;
-    __device__ bool put(int e, uint64_t x0, uint64_t size, int end) {
-        const uint32_t w2 = (uint32_t)(x0 >> 32) | (uint32_t)(size >> 32) << 5 | (uint32_t)end << 10;
-        if (e < K) { v0[e * 64] = (uint32_t)x0; v1[e * 64] = (uint32_t)size; v2[e * 64] = w2; return true; }
-        if (e - K >= spill_cap) return false;
-        uint4 t; t.x = (uint32_t)x0; t.y = (uint32_t)size; t.z = w2; t.w = 0;
-        spill[(size_t)(e - K) * 64] = t;
+    static __device__ uint32_t pack2(uint64_t x0, uint64_t size, int end) { return (uint32_t)(x0 >> 32) | (uint32_t)(size >> 32) << 5 | (uint32_t)end << 10; }
+    // forward phase: entry e becomes the new top (height e + 1); the entry leaving the ring goes to the global area
+    __device__ bool push(int e, uint64_t x0, uint64_t size, int end) {
+        const int s = (e & (K - 1)) * 64;
+        if (e >= K) {
+            if (e - K >= spill_cap) return false;
+            uint4 t; t.x = v0[s]; t.y = v1[s]; t.z = v2[s]; t.w = 0;
+            spill[(size_t)(e - K) * 64] = t;
+        }
+        v0[s] = (uint32_t)x0; v1[s] = (uint32_t)size; v2[s] = pack2(x0, size, end);
         return true;
     }
-    __device__ void get(int e, uint64_t& x0, uint64_t& size, int& end) const {
+    // backward phase, stack height n fixed: entries n-K .. n-1 are in the ring
+    __device__ void put(int e, int n, uint64_t x0, uint64_t size, int end) {
+        if (e >= n - K) { const int s = (e & (K - 1)) * 64; v0[s] = (uint32_t)x0; v1[s] = (uint32_t)size; v2[s] = pack2(x0, size, end); }
+        else { uint4 t; t.x = (uint32_t)x0; t.y = (uint32_t)size; t.z = pack2(x0, size, end); t.w = 0; spill[(size_t)e * 64] = t; }
+    }
+    __device__ void get(int e, int n, uint64_t& x0, uint64_t& size, int& end) const {
         uint32_t a, b, w2;
-        if (e < K) { a = v0[e * 64]; b = v1[e * 64]; w2 = v2[e * 64]; }
-        else { const uint4 t = spill[(size_t)(e - K) * 64]; a = t.x; b = t.y; w2 = t.z; }
+        if (e >= n - K) { const int s = (e & (K - 1)) * 64; a = v0[s]; b = v1[s]; w2 = v2[s]; }
+        else { const uint4 t = spill[(size_t)e * 64]; a = t.x; b = t.y; w2 = t.z; }
         x0 = (uint64_t)(w2 & 31) << 32 | a; size = (uint64_t)(w2 >> 5 & 31) << 32 | b; end = (int)(w2 >> 10);
     }
 };
@@ -109,18 +120,16 @@ __global__ void k_encode(uint8_t* seq, int64_t n_bytes)
 // (bwt_smem1 / bwt_seed_strategy1 / mem_collect_intv); only the order of equal-priority list entries before the final
 // sort differs, which the sort removes.
 enum { S_IDLE = 0, S_NEXT = 1, S_FWD = 2, S_BWD = 3, S_P3 = 4 };
-#define SEED_REFILL_MIN 4
 
 template <bool LDSQ>
-__global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView tv, int K)
+__global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView tv, int K, int refill_min)
 {
     HIP_DYNAMIC_SHARED(uint32_t, lds)
     const int lane = threadIdx.x;
     CandStack V;
     V.v0 = lds + lane; V.v1 = V.v0 + K * 64; V.v2 = V.v1 + K * 64; V.K = K;
     V.spill = (uint4*)tv.smem_scratch + (size_t)blockIdx.x * tv.smem_cap * 64 + lane; V.spill_cap = tv.smem_cap;
-    uint8_t* sq = (uint8_t*)(lds + 3 * K * 64);          // [64 lanes][qs] base codes of the lanes' current reads
-    const int qs = tv.max_len + 1;
+    uint32_t* sq = lds + 3 * K * 64 + lane;              // [word][64 lanes]: the lanes' current reads, 8 base codes per word
     unsigned int* work = (unsigned int*)(tv.err + 8);    // next unclaimed read of the tile
     const int min_seed_len = opt.min_seed_len;
     const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
@@ -134,16 +143,16 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
     Intv* mem = tv.intv;
     uint32_t n_ext = 0;
 
-#define QAT(p) (LDSQ ? (int)sq[lane * qs + (p)] : (int)qg[(p)])
+#define QAT(p) (LDSQ ? (int)(sq[((p) >> 3) * 64] >> (((p) & 7) << 2) & 15u) : (int)qg[(p)])
 #define FINISH() do { tv.n_intv[r] = ovf ? 0 : mem_n; if (ovf) atomicOr(tv.err, ERR_INTV_CAP); st = S_IDLE; } while (0)
 #define MEM_PUSH(X0, SZ, INFO) do { if (mem_n >= tv.intv_cap) ovf = true; else { Intv v_; v_.x0 = (X0); v_.x1 = 0; v_.size = (SZ); v_.info = (INFO); mem[mem_n++] = v_; } } while (0)
-#define PUSH_IK() do { if (V.put(nf, ik0, iks, end)) ++nf; else ovf = true; } while (0)
+#define PUSH_IK() do { if (V.push(nf, ik0, iks, end)) ++nf; else ovf = true; } while (0)
 #define BEGIN_BWD() do { ret = end; lo = 0; rd = wr = nf - 1; i = sx - 1; c = i >= 0 ? QAT(i) : 4; c = c < 4 ? c : -1; st = S_BWD; } while (0)
 
     for (;;) {
         // ---- work queue: idle lanes claim the next reads of the tile, the wave stages them in LDS together
         const unsigned long long idle = __ballot(st == S_IDLE);
-        if (idle != 0ull && !exhausted && (__popcll(idle) >= SEED_REFILL_MIN || idle == ~0ull)) {
+        if (idle != 0ull && !exhausted && (__popcll(idle) >= refill_min || idle == ~0ull)) {
             const int n_need = __popcll(idle);
             unsigned int base = 0;
             if (lane == 0) base = atomicAdd(work, (unsigned int)n_need);
@@ -168,8 +177,12 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
                     got &= got - 1ull;
                     const int rr = __shfl(r, l);
                     const int64_t off = tv.seq_off[rr];
-                    const int nb = (int)(tv.seq_off[rr + 1] - off);
-                    for (int k = lane; k < nb; k += 64) sq[l * qs + k] = tv.seq[off + k];
+                    const int nb = (int)(tv.seq_off[rr + 1] - off) - 1;
+                    for (int k = lane; k * 8 < nb; k += 64) {           // lane k packs bases 8k .. 8k+7 of the read claimed by lane l
+                        uint32_t wd = 0;
+                        for (int b = 0; b < 8; ++b) { const int pos = k * 8 + b; wd |= (uint32_t)(pos < nb ? tv.seq[off + pos] & 15 : 4) << (b << 2); }
+                        sq[k * 64 + (l - lane)] = wd;
+                    }
                 }
                 __syncthreads();
             }
@@ -226,7 +239,7 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
             } else { x = i < len ? i + 1 : len; st = S_NEXT; }      // bwt_seed_strategy1 found nothing from sx
         }
         if (st == S_BWD) {
-            V.get(rd, r0, rs, pend);
+            V.get(rd, nf, r0, rs, pend);
             bw = true;
             if (c >= 0) { need = true; back = true; rc = c; }
         }
@@ -243,7 +256,7 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
                     if (pend - (i + 1) >= min_seed_len) MEM_PUSH(r0, rs, (uint64_t)(i + 1) << 32 | (uint32_t)pend);
                 }
             } else if (wr == nf - 1 || os != last_sz) {             // survivor; rows are compacted in place, longest on top
-                V.put(wr, o0, os, pend); --wr; last_sz = os;
+                V.put(wr, nf, o0, os, pend); --wr; last_sz = os;
             }
             --rd;
             if (rd < lo) {                                          // row complete
@@ -314,29 +327,33 @@ __global__ void k_seed_fin(MemOpt opt, TileView tv)
     tv.l_rep[r] = l_rep;
 }
 
-// exclusive scan int32 -> int64 (single workgroup; n is a tile's read count, so this is tiny)
-__global__ void k_scan(const int32_t* in, int64_t* out, int n)
+// exclusive scan int32 -> int64 of a tile's per-read counts.  One workgroup walks the array in tiles of 4096: coalesced
+// 16-byte loads, a 4-element serial prefix per thread, a shuffle scan per wave, the 16 wave totals through LDS, and a
+// running carry between tiles.
+__global__ void __launch_bounds__(1024) k_scan(const int32_t* in, int64_t* out, int n)
 {
-    __shared__ int64_t part[1024];
-    __shared__ int64_t carry;
-    int t = threadIdx.x, nt = blockDim.x;
-    if (t == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += nt) {
-        int i = base + t;
-        int64_t v = i < n ? in[i] : 0;
-        part[t] = v;
+    __shared__ int64_t wtot[2][16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int64_t carry = 0;
+    int ph = 0;
+    for (int base = 0; base < n; base += 4096, ph ^= 1) {
+        const int i0 = base + t * 4;
+        int v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        if (i0 + 3 < n) { const int4 q = *(const int4*)(in + i0); v0 = q.x; v1 = q.y; v2 = q.z; v3 = q.w; }
+        else { if (i0 < n) v0 = in[i0]; if (i0 + 1 < n) v1 = in[i0 + 1]; if (i0 + 2 < n) v2 = in[i0 + 2]; }
+        const int64_t sum = (int64_t)v0 + v1 + v2 + v3;
+        int64_t incl = sum;
+        for (int o = 1; o < 64; o <<= 1) { int64_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+        if (lane == 63) wtot[ph][wv] = incl;
         __syncthreads();
-        for (int o = 1; o < nt; o <<= 1) {
-            int64_t add = t >= o ? part[t - o] : 0;
-            __syncthreads();
-            part[t] += add;
-            __syncthreads();
-        }
-        if (i < n) out[i] = carry + part[t] - v;
-        __syncthreads();
-        if (t == nt - 1) carry += part[t];
-        __syncthreads();
+        int64_t pre = carry, tot = 0;
+        for (int w = 0; w < 16; ++w) { const int64_t x = wtot[ph][w]; if (w < wv) pre += x; tot += x; }
+        int64_t run = pre + incl - sum;
+        if (i0 < n) out[i0] = run;
+        run += v0; if (i0 + 1 < n) out[i0 + 1] = run;
+        run += v1; if (i0 + 2 < n) out[i0 + 2] = run;
+        run += v2; if (i0 + 3 < n) out[i0 + 3] = run;
+        carry += tot;
     }
     if (t == 0) out[n] = carry;
 }
@@ -409,17 +426,19 @@ void launch_seed(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const Ti
     if (tv.n_reads <= 0) return;
     static int n_cu = 0;
     if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
-    int K = 32, wpc = 0;
+    int K = 16, wpc = 0, refill_min = 4;
+    { const char* e = getenv("BWAMEM_HIP_SEED_REFILL"); if (e && atoi(e) > 0) refill_min = atoi(e); }
     { const char* e = getenv("BWAMEM_HIP_SEED_K"); if (e && atoi(e) > 0) K = atoi(e); }
     { const char* e = getenv("BWAMEM_HIP_SEED_WPC"); if (e && atoi(e) > 0) wpc = atoi(e); }
-    const size_t qbytes = (size_t)64 * ((size_t)tv.max_len + 1);
+    while (K & (K - 1)) K &= K - 1;                                  // the candidate ring needs a power of two
+    const size_t qbytes = (size_t)64 * 4 * (((size_t)tv.max_len + 7) / 8);
     const bool ldsq = qbytes <= 24576;
     const size_t lds = (size_t)3 * K * 64 * 4 + (ldsq ? qbytes : 0) + 16;
     if (!wpc) { wpc = (int)((size_t)(160 * 1024) / ((lds + 1023) & ~(size_t)1023)); wpc = wpc < 1 ? 1 : wpc > 16 ? 16 : wpc; }
     const int groups = (tv.n_reads + 63) / 64;
     const int grid = groups < n_cu * wpc ? groups : n_cu * wpc;
-    if (ldsq) hipLaunchKernelGGL(k_seed<true>, dim3(grid), dim3(64), lds, st, ix, opt, tv, K);
-    else hipLaunchKernelGGL(k_seed<false>, dim3(grid), dim3(64), lds, st, ix, opt, tv, K);
+    if (ldsq) hipLaunchKernelGGL(k_seed<true>, dim3(grid), dim3(64), lds, st, ix, opt, tv, K, refill_min);
+    else hipLaunchKernelGGL(k_seed<false>, dim3(grid), dim3(64), lds, st, ix, opt, tv, K, refill_min);
     hipLaunchKernelGGL(k_seed_fin, dim3((tv.n_reads + 255) / 256), dim3(256), 0, st, opt, tv);
 }
 void launch_scan(hipStream_t st, const int32_t* in, int64_t* out, int n)

@@ -33,6 +33,7 @@ static __device__ inline bool wave_any(int pred) { return __ballot(pred) != 0ull
 // gfx9 controls: row_shr:n = 0x110+n (within a 16-lane row), wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
 #define DPP_ROW_SHR(n) (0x110 + (n))
 #define DPP_WAVE_SHR1 0x138
+#define DPP_WAVE_SHL1 0x130
 #define DPP_ROW_BCAST15 0x142
 #define DPP_ROW_BCAST31 0x143
 
@@ -52,5 +53,7 @@ static __device__ inline int dpp_prefix_max(int v, int /*neg*/)
 }
 // lane l <- lane l-1; lane 0 <- fill
 static __device__ inline int dpp_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHR1, 0xf, 0xf, false); }
+// lane l <- lane l+1; lane 63 <- fill
+static __device__ inline int dpp_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHL1, 0xf, 0xf, false); }
 // value of a (wave-uniform) lane as a scalar
 static __device__ inline int wave_readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }

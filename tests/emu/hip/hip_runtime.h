@@ -25,6 +25,7 @@
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct uint4 { uint32_t x, y, z, w; };
+struct int4 { int32_t x, y, z, w; };
 
 extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 
@@ -85,6 +86,7 @@ static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int b
     int from = -1;
     if (ctrl >= 0x111 && ctrl <= 0x11f) { int n = ctrl - 0x110; from = in_row >= n ? lane - n : -1; }
     else if (ctrl == 0x138) from = lane >= 1 ? lane - 1 : -1;
+    else if (ctrl == 0x130) from = lane < 63 ? lane + 1 : -1;
     else if (ctrl == 0x142) from = row >= 1 ? (row << 4) - 1 : -1;
     else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;
     else { fprintf(stderr, "emu: unsupported DPP control 0x%x\n", ctrl); abort(); }
