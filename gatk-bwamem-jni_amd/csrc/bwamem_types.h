@@ -148,7 +148,8 @@ struct TileView {
     // global-alignment jobs (single-end): regions whose CIGAR needs DP, compacted for the wave-parallel kernel
     int32_t* job_cnt;             // [1]
     void* jobs;                   // DpJob[job_cap]
-    int32_t job_cap, pad2_;
+    int32_t job_cap;
+    int32_t smem_groups;          // workgroups the smem_scratch spill area covers (upper bound for the k_seed grid)
     int32_t debug;                // BWAMEM_HIP_DEBUGK: device-side progress prints (debugging aid)
     int32_t pad_;
 };

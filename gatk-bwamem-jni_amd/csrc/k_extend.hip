@@ -17,6 +17,21 @@ struct ExtRes { int score, qle, tle, gtle, gscore, max_off; };
 
 struct ExtLds { int32_t* eh_h; int32_t* eh_e; int32_t* tmpM; const uint8_t* query; };
 
+// Early exit of the extension DP (both forms below).  Upstream's ksw_extend2 keeps computing rows until the target
+// runs out, the row maximum is 0 or the z-drop test fires; for a query that has been matched to its end that means
+// up to |query| further rows of slowly decaying deletion scores that change nothing.  After a row, every score a later
+// row can still produce derives from the stored state {h[j] = H(i,j-1), e[j] = E(i+1,j)}, j >= beg, and from the
+// first-column values still to be injected: moving down never gains, moving one column right gains at most mx.  Hence
+// B = max_j (max(h[j] + mx, e[j]) + mx * (qlen-1-j)) bounds all later H.  When B <= max (the maximum can no longer be
+// beaten: updates need m > max) and B < gscore (the to-end score and its row cannot change: updates need h1 >= gscore),
+// the outputs are final and the loop stops -- same result, fewer rows.
+static __device__ inline int ext_bound_term(int h, int e, int mx, int cols_right)
+{
+    int v = h > 0 ? h + mx : 0;                               // M of the next row is 0 for a dead predecessor
+    v = v > e ? v : e;
+    return v > 0 ? v + mx * cols_right : 0;
+}
+
 // ksw_extend2 with the query read as query[q0 + qstep*j] and the target as the doubled-strand
 // reference base at t0 + tstep*i.
 static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, const ExtLds& L, int lane,
@@ -38,8 +53,8 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
         }
         L.eh_h[j] = v; L.eh_e[j] = 0;
     }
+    const int mx = score_max(opt);
     {   // clip the band by the longest affordable gap
-        const int mx = score_max(opt);
         max_ins = (int)((double)(qlen * mx + end_bonus - o_ins) / e_ins + 1.);
         max_ins = max_ins > 1 ? max_ins : 1;
         w = w < max_ins ? w : max_ins;
@@ -156,6 +171,17 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
             end = jl + 2 < qlen ? jl + 2 : qlen;
         }
         __syncthreads();
+        if (gscore > 0 && m + mx * (qlen - 1 - mj) <= max) {   // see ext_bound(): the remaining rows cannot change the result
+            int B = 0;
+            for (int c = beg; c < qlen; c += WAVE) {
+                const int j = c + lane;
+                const int term = j < qlen ? ext_bound_term(L.eh_h[j], L.eh_e[j], mx, qlen - 1 - j) : 0;
+                const int bc = wave_max(term);
+                B = B > bc ? B : bc;
+            }
+            if (beg == 0) { const int hb = h0 - (o_del + e_del * (i + 2)); if (hb > 0 && hb + mx * qlen > B) B = hb + mx * qlen; }
+            if (B <= max && B < gscore) break;
+        }
     }
     __syncthreads();
     ExtRes r;
@@ -191,8 +217,8 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
         ehh[t] = v; ehe[t] = 0;
         score_lane(ST, j < qlen ? query[q0 + qstep * j] : 4, scp[t], scn[t]);
     }
+    const int mx = score_max(opt);
     {
-        const int mx = score_max(opt);
         max_ins = (int)((double)(qlen * mx + end_bonus - o_ins) / e_ins + 1.);
         max_ins = max_ins > 1 ? max_ins : 1;
         w = w < max_ins ? w : max_ins;
@@ -296,6 +322,18 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
             if (jl == -2) jl = beg - 1;
             end = jl + 2 < qlen ? jl + 2 : qlen;
         }
+        if (gscore > 0 && m + mx * (qlen - 1 - mj) <= max) {   // see ext_bound(): the remaining rows cannot change the result
+            int B = 0;
+#pragma unroll
+            for (int t = 0; t < C; ++t) {
+                const int j = t * WAVE + lane;
+                const int term = j >= beg && j < qlen ? ext_bound_term(ehh[t], ehe[t], mx, qlen - 1 - j) : 0;
+                const int bc = wave_readlane(dpp_prefix_max(term, 0), 63);
+                B = B > bc ? B : bc;
+            }
+            if (beg == 0) { const int hb = h0 - (o_del + e_del * (i + 2)); if (hb > 0 && hb + mx * qlen > B) B = hb + mx * qlen; }
+            if (B <= max && B < gscore) break;
+        }
     }
     ExtRes r;
     r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
@@ -320,7 +358,7 @@ struct U64Lt { __device__ bool operator()(uint64_t a, uint64_t b) const { return
 // minimum resident waves per SIMD the register allocator must leave room for (the DP rows are one long dependent
 // chain per wave, so latency hiding comes from co-resident waves)
 #ifndef K_EXTEND_MIN_WAVES
-#define K_EXTEND_MIN_WAVES 4
+#define K_EXTEND_MIN_WAVES 8
 #endif
 __global__ void __launch_bounds__(64, K_EXTEND_MIN_WAVES) k_extend(DevIndex ix, MemOpt opt, TileView tv)
 {

@@ -120,6 +120,7 @@ __global__ void k_encode(uint8_t* seq, int64_t n_bytes)
 // (bwt_smem1 / bwt_seed_strategy1 / mem_collect_intv); only the order of equal-priority list entries before the final
 // sort differs, which the sort removes.
 enum { S_IDLE = 0, S_NEXT = 1, S_FWD = 2, S_BWD = 3, S_P3 = 4 };
+#define SEED_EL_CAP 4
 
 template <bool LDSQ>
 __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView tv, int K, int refill_min)
@@ -129,22 +130,24 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
     CandStack V;
     V.v0 = lds + lane; V.v1 = V.v0 + K * 64; V.v2 = V.v1 + K * 64; V.K = K;
     V.spill = (uint4*)tv.smem_scratch + (size_t)blockIdx.x * tv.smem_cap * 64 + lane; V.spill_cap = tv.smem_cap;
-    uint32_t* sq = lds + 3 * K * 64 + lane;              // [word][64 lanes]: the lanes' current reads, 8 base codes per word
+    uint32_t* el = lds + 3 * K * 64 + lane;              // [SEED_EL_CAP][64 lanes]: pass-1 matches that pass 2 re-seeds (mid:17 | size:15)
+    uint32_t* sq = el + SEED_EL_CAP * 64;                // [word][64 lanes]: the lanes' current reads, 8 base codes per word
     unsigned int* work = (unsigned int*)(tv.err + 8);    // next unclaimed read of the tile
     const int min_seed_len = opt.min_seed_len;
     const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
     const uint64_t max_intv3 = (uint64_t)(int64_t)(int)opt.max_mem_intv;
 
     int st = S_IDLE, r = 0, len = 0, pass = 1, x = 0, sx = 0, i = 0, k2 = 0, old_n = 0, mem_n = 0;
-    int nf = 0, lo = 0, rd = 0, wr = 0, c = -1, ret = 0, end = 0;
+    int nf = 0, lo = 0, rd = 0, wr = 0, c = -1, ret = 0, end = 0, n_el = 0;
     uint64_t min_intv = 1, last_start = 0, last_sz = 0, ik0 = 0, ik1 = 0, iks = 0;
-    bool any = false, ovf = false, exhausted = false;
+    bool any = false, ovf = false, exhausted = false, el_ok = true;
     const uint8_t* qg = tv.seq;
     Intv* mem = tv.intv;
-    uint32_t n_ext = 0;
+    uint32_t n_ext = 0, ext0 = 0;                        // ext0: n_ext when the current read was claimed (BWAMEM_HIP_SEEDSTAT statistics)
 
 #define QAT(p) (LDSQ ? (int)(sq[((p) >> 3) * 64] >> (((p) & 7) << 2) & 15u) : (int)qg[(p)])
-#define FINISH() do { tv.n_intv[r] = ovf ? 0 : mem_n; if (ovf) atomicOr(tv.err, ERR_INTV_CAP); st = S_IDLE; } while (0)
+#define FINISH() do { tv.n_intv[r] = ovf ? 0 : mem_n; if (ovf) atomicOr(tv.err, ERR_INTV_CAP); st = S_IDLE; \
+        if (tv.debug & 4) { const int d_ = (int)(n_ext - ext0); atomicMax(tv.err + 9, d_); atomicAdd(tv.err + 10 + (d_ < 1000 ? 0 : d_ < 2000 ? 1 : d_ < 4000 ? 2 : d_ < 8000 ? 3 : d_ < 16000 ? 4 : 5), 1); } } while (0)
 #define MEM_PUSH(X0, SZ, INFO) do { if (mem_n >= tv.intv_cap) ovf = true; else { Intv v_; v_.x0 = (X0); v_.x1 = 0; v_.size = (SZ); v_.info = (INFO); mem[mem_n++] = v_; } } while (0)
 #define PUSH_IK() do { if (V.push(nf, ik0, iks, end)) ++nf; else ovf = true; } while (0)
 #define BEGIN_BWD() do { ret = end; lo = 0; rd = wr = nf - 1; i = sx - 1; c = i >= 0 ? QAT(i) : 4; c = c < 4 ? c : -1; st = S_BWD; } while (0)
@@ -167,7 +170,7 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
                     len = (int)(tv.seq_off[r + 1] - off - 1);
                     qg = tv.seq + off;
                     mem = tv.intv + (size_t)r * tv.intv_cap;
-                    mem_n = 0; ovf = false; pass = 1; x = 0; st = S_NEXT;
+                    mem_n = 0; ovf = false; pass = 1; x = 0; st = S_NEXT; n_el = 0; el_ok = true; ext0 = n_ext;
                 }
             }
             if (LDSQ) {
@@ -198,7 +201,15 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
                 if (x >= len) { pass = 2; old_n = mem_n; k2 = 0; }
                 else if (QAT(x) > 3) ++x;
                 else nx = x;
-            } else if (pass == 2) {
+            } else if (pass == 2 && el_ok) {                        // the common case: candidates remembered in LDS
+                if (k2 >= n_el) { pass = 3; x = 0; if (!(opt.max_mem_intv > 0)) FINISH(); }
+                else {
+                    const uint32_t wd = el[k2 * 64];
+                    const int m = (int)(wd & 0x1ffffu);
+                    if (QAT(m) > 3) ++k2;                           // bwt_smem1 returns at once on an ambiguous base
+                    else { nx = m; nmin = (uint64_t)(wd >> 17) + 1; }
+                }
+            } else if (pass == 2) {                                 // more candidates than LDS slots: walk the list itself
                 if (k2 >= old_n) { pass = 3; x = 0; if (!(opt.max_mem_intv > 0)) FINISH(); }
                 else {
                     const uint64_t psz = mem[k2].size, pinfo = mem[k2].info;
@@ -206,7 +217,7 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
                     if (e0 - s0 < split_len || psz > (uint64_t)(int64_t)opt.split_width) ++k2;
                     else {
                         const int m = (s0 + e0) >> 1;
-                        if (QAT(m) > 3) ++k2;                       // bwt_smem1 returns at once on an ambiguous base
+                        if (QAT(m) > 3) ++k2;
                         else { nx = m; nmin = psz + 1; }
                     }
                 }
@@ -253,7 +264,16 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
             if (!need || os < min_intv) {                           // cannot be extended to i: a match starts at i + 1
                 if (wr == nf - 1 && (!any || (uint64_t)(i + 1) < last_start)) {
                     any = true; last_start = (uint64_t)(i + 1);
-                    if (pend - (i + 1) >= min_seed_len) MEM_PUSH(r0, rs, (uint64_t)(i + 1) << 32 | (uint32_t)pend);
+                    if (pend - (i + 1) >= min_seed_len) {
+                        MEM_PUSH(r0, rs, (uint64_t)(i + 1) << 32 | (uint32_t)pend);
+                        // pass 2 re-seeds long matches with few occurrences from their middle: remember those as they
+                        // are found, so that pass 2 does not have to read the list back from global memory
+                        if (pass == 1 && pend - (i + 1) >= split_len && rs <= (uint64_t)(int64_t)opt.split_width) {
+                            if (n_el < SEED_EL_CAP && rs < 32768u) el[n_el * 64] = (uint32_t)((i + 1 + pend) >> 1) | (uint32_t)rs << 17;
+                            else el_ok = false;
+                            ++n_el;
+                        }
+                    }
                 }
             } else if (wr == nf - 1 || os != last_sz) {             // survivor; rows are compacted in place, longest on top
                 V.put(wr, nf, o0, os, pend); --wr; last_sz = os;
@@ -433,10 +453,11 @@ void launch_seed(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const Ti
     while (K & (K - 1)) K &= K - 1;                                  // the candidate ring needs a power of two
     const size_t qbytes = (size_t)64 * 4 * (((size_t)tv.max_len + 7) / 8);
     const bool ldsq = qbytes <= 24576;
-    const size_t lds = (size_t)3 * K * 64 * 4 + (ldsq ? qbytes : 0) + 16;
+    const size_t lds = (size_t)3 * K * 64 * 4 + (size_t)SEED_EL_CAP * 64 * 4 + (ldsq ? qbytes : 0) + 16;
     if (!wpc) { wpc = (int)((size_t)(160 * 1024) / ((lds + 1023) & ~(size_t)1023)); wpc = wpc < 1 ? 1 : wpc > 16 ? 16 : wpc; }
     const int groups = (tv.n_reads + 63) / 64;
-    const int grid = groups < n_cu * wpc ? groups : n_cu * wpc;
+    int grid = groups < n_cu * wpc ? groups : n_cu * wpc;
+    if (tv.smem_groups > 0 && grid > tv.smem_groups) grid = tv.smem_groups;
     if (ldsq) hipLaunchKernelGGL(k_seed<true>, dim3(grid), dim3(64), lds, st, ix, opt, tv, K, refill_min);
     else hipLaunchKernelGGL(k_seed<false>, dim3(grid), dim3(64), lds, st, ix, opt, tv, K, refill_min);
     hipLaunchKernelGGL(k_seed_fin, dim3((tv.n_reads + 255) / 256), dim3(256), 0, st, opt, tv);

@@ -17,6 +17,7 @@
 #include <sys/stat.h>
 #include <sys/mman.h>
 #include <mutex>
+#include <condition_variable>
 #include <thread>
 #include <atomic>
 #include <string>
@@ -70,11 +71,13 @@ struct Workspace {
     hipStream_t stream = nullptr;
     std::vector<Timed> timed;
 
-    bool ensure_reads(int T_, int L_, int intv_cap_, int out_cap_, int64_t post_per_read_) {
+    // with_seed = false: the tile takes its interval lists from a SeedStore (single-end path) and needs no seeding arrays
+    bool ensure_reads(int T_, int L_, int intv_cap_, int out_cap_, int64_t post_per_read_, bool with_seed = true) {
         T = T_; L = L_; intv_cap = intv_cap_; smem_cap = L_ + 2; out_cap = out_cap_; post_per_read = post_per_read_;
         size_t t = (size_t)T;
-        return intv.ensure(t * intv_cap * sizeof(Intv)) && n_intv.ensure(t * 4) && smem.ensure(((t + 63) / 64 * 64) * 2 * smem_cap * 16)
-            && l_rep.ensure(t * 4) && n_seeds.ensure(t * 4) && seed_off.ensure((t + 1) * 8) && intv_seed_off.ensure(t * intv_cap * 4)
+        if (with_seed && !(intv.ensure(t * intv_cap * sizeof(Intv)) && n_intv.ensure(t * 4) && smem.ensure(((t + 63) / 64 * 64) * 2 * smem_cap * 16)
+            && l_rep.ensure(t * 4) && n_seeds.ensure(t * 4) && intv_seed_off.ensure(t * intv_cap * 4))) return false;
+        return seed_off.ensure((t + 1) * 8)
             && n_chains.ensure(t * 4) && n_regs.ensure(t * 4) && out.ensure(t * out_cap) && out_len.ensure(t * 4)
             && out_off.ensure((t + 1) * 8) && post.ensure(t * (size_t)post_per_read) && err.ensure(64) && cnt.ensure(sizeof(DevCounters));
     }
@@ -109,9 +112,24 @@ struct Workspace {
         tv.post_scratch = post.as<uint8_t>(); tv.post_scratch_per_read = post_per_read;
         tv.err = err.as<int32_t>(); tv.cnt = cnt.as<DevCounters>();
         tv.job_cnt = job_cnt.as<int32_t>(); tv.jobs = jobs.p; tv.job_cap = job_cap;
+        tv.smem_groups = (T + 63) / 64;
         { const char* e = getenv("BWAMEM_HIP_DEBUGK"); tv.debug = e ? atoi(e) : 0; }
         return tv;
     }
+};
+
+// Interval lists of one seeding chunk (single-end path): k_seed runs over chunks of a few million reads -- several
+// tiles -- because its running time is bounded below by the slowest read of a launch; the tiles of the chunk then
+// point their TileView at slices of these arrays.
+struct SeedStore {
+    DevBuf intv, n_intv, intv_seed_off, n_seeds, l_rep;
+    int cap = 0;                      // intervals per read
+    bool ensure(size_t reads, int cap_) {
+        cap = cap_;
+        return intv.ensure(reads * cap * sizeof(Intv)) && n_intv.ensure(reads * 4) && intv_seed_off.ensure(reads * cap * 4)
+            && n_seeds.ensure(reads * 4) && l_rep.ensure(reads * 4);
+    }
+    void release() { intv.release(); n_intv.release(); intv_seed_off.release(); n_seeds.release(); l_rep.release(); }
 };
 
 struct bwaidx_s {
@@ -123,6 +141,8 @@ struct bwaidx_s {
     std::mutex mu;                  // one call at a time per index/device
     Workspace ws;
     std::vector<Workspace*> extra_ws;   // further tiles in flight (one stream + host thread each)
+    Workspace seed_ws;                  // stream, flags and spill area of the seeding stage (single-end path)
+    SeedStore seed_store[2];            // double-buffered: chunk c+1 is seeded while the tiles of chunk c run
 };
 
 struct TileOut { uint8_t* d = nullptr; size_t bytes = 0; };
@@ -195,6 +215,8 @@ static void free_index(bwaidx_s* ix)
     DevBuf* all[] = { &ix->d_occ, &ix->d_sa, &ix->d_pac, &ix->d_ann_off, &ix->d_ann_len, &ix->d_ann_alt, &ix->d_name_off, &ix->d_names, &ix->d_log };
     for (DevBuf* b : all) b->release();
     ix->ws.release();
+    ix->seed_ws.release();
+    ix->seed_store[0].release(); ix->seed_store[1].release();
     for (Workspace* w : ix->extra_ws) { w->release(); delete w; }
     ix->extra_ws.clear();
 }
@@ -509,38 +531,85 @@ static std::vector<TileSpec> plan_tiles(const bwamem_batch_s* b, const MemOpt& o
     return tiles;
 }
 
+// The seeding stage of the single-end path: k_seed + k_seed_fin over one chunk of reads (several tiles), on the seeding
+// workspace's stream, into one of the two interval stores.
+struct SeedChunk { uint32_t r0 = 0, r1 = 0; int L = 1; size_t tile0 = 0, tile1 = 0; int state = 0; size_t tiles_left = 0; };   // state: 0 pending, 1 ready, -1 failed
+
+static bool seed_chunk(bwaidx_s* ix, const MemOpt& opt, bwamem_batch_s* b, const SeedChunk& ch, SeedStore& store, int& intv_cap_scale)
+{
+    Workspace& sw = ix->seed_ws;
+    if (!sw.stream) HIP_OK(hipStreamCreate(&sw.stream));
+    const int T = (int)(ch.r1 - ch.r0), L = ch.L;
+    const int max_groups = 8192;                                 // upper bound on the persistent k_seed grid
+    const int groups = std::min(max_groups, (T + 63) / 64);
+    for (int attempts = 0; attempts < 8; ++attempts) {
+        const int cap = std::max(64, L + 8) * intv_cap_scale;
+        if (!store.ensure((size_t)T, cap)) return false;
+        if (!sw.err.ensure(64) || !sw.cnt.ensure(sizeof(DevCounters)) || !sw.smem.ensure((size_t)groups * (L + 2) * 64 * 16)) return false;
+        TileView tv; memset(&tv, 0, sizeof tv);
+        tv.n_reads = T; tv.max_len = L;
+        tv.seq = b->d_seq.as<uint8_t>(); tv.seq_off = b->d_off.as<int64_t>() + ch.r0;
+        tv.intv_cap = cap; tv.intv = store.intv.as<Intv>(); tv.n_intv = store.n_intv.as<int32_t>();
+        tv.intv_seed_off = store.intv_seed_off.as<int32_t>(); tv.n_seeds = store.n_seeds.as<int32_t>(); tv.l_rep = store.l_rep.as<int32_t>();
+        tv.smem_scratch = sw.smem.as<Intv>(); tv.smem_cap = L + 2; tv.smem_groups = groups;
+        tv.err = sw.err.as<int32_t>(); tv.cnt = sw.cnt.as<DevCounters>();
+        tv.debug = getenv("BWAMEM_HIP_SEEDSTAT") ? 4 : 0;          // per-read extension-count statistics (diagnostics)
+        HIP_OK(hipMemsetAsync(sw.err.p, 0, 64, sw.stream));
+        HIP_OK(hipMemsetAsync(sw.cnt.p, 0, sizeof(DevCounters), sw.stream));
+        TIMED(sw, K_SEED, launch_seed(sw.stream, ix->d, opt, tv));
+        int32_t h[16]; DevCounters hc;
+        HIP_OK(hipMemcpyAsync(h, tv.err, sizeof h, hipMemcpyDeviceToHost, sw.stream));
+        HIP_OK(hipMemcpyAsync(&hc, tv.cnt, sizeof hc, hipMemcpyDeviceToHost, sw.stream));
+        HIP_OK(hipStreamSynchronize(sw.stream));
+        timed_collect(sw);
+        if (tv.debug & 4)
+            fprintf(stderr, "[bwamem_hip] k_seed chunk of %d reads: max extensions/read %d; reads with <1k %d <2k %d <4k %d <8k %d <16k %d more %d\n", T, h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
+        if (h[0] & ERR_INTV_CAP) { intv_cap_scale *= 2; { std::lock_guard<std::mutex> lk(g_stats.mu); ++g_stats.s.n_retries; } continue; }
+        { std::lock_guard<std::mutex> lk(g_stats.mu); g_stats.s.n_ext += hc.n_ext; }
+        return true;
+    }
+    fprintf(stderr, "[bwamem_hip] seeding chunk could not be sized after 8 attempts\n");
+    return false;
+}
+
 // one single-end tile, start to packed response, on the workspace's own stream
 static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_batch_s* b, int64_t read_id0, const TileSpec& spec,
-                        TileOut& to, int& intv_cap_scale, int& out_cap)
+                        TileOut& to, const SeedStore& seeds_of_chunk, uint32_t chunk_r0, int& out_cap)
 {
     const uint32_t r0 = spec.r0;
     const int T = (int)(spec.r1 - spec.r0), L = spec.L;
-    int intv_cap = std::max(64, L + 8) * intv_cap_scale;
     int attempts = 0, job_cap_hint = 0;
     size_t zpool_hint = (size_t)64 << 20;
     for (;;) {
         if (++attempts > 8) { fprintf(stderr, "[bwamem_hip] tile could not be sized after 8 attempts\n"); return false; }
-        if (!ws.ensure_reads(T, L, intv_cap, out_cap, post_bytes_per_read(L, opt, false))) return false;
+        if (!ws.ensure_reads(T, L, seeds_of_chunk.cap, out_cap, post_bytes_per_read(L, opt, false), false)) return false;
         if (!ws.ensure_seeds(std::max<int64_t>(ws.seed_cap, (int64_t)T * 16))) return false;
         if (!ws.ensure_jobs(std::max(job_cap_hint, std::max(1024, T / 4)), 4 * L + 16, zpool_hint)) return false;
-        TileView tv = ws.view();
-        tv.n_reads = T; tv.max_len = L; tv.read_id0 = read_id0 + r0;
-        tv.seq = b->d_seq.as<uint8_t>(); tv.seq_off = b->d_off.as<int64_t>() + r0;
+        auto make_view = [&]() {
+            TileView v = ws.view();
+            v.n_reads = T; v.max_len = L; v.read_id0 = read_id0 + r0;
+            v.seq = b->d_seq.as<uint8_t>(); v.seq_off = b->d_off.as<int64_t>() + r0;
+            const size_t at = (size_t)(r0 - chunk_r0);              // this tile's slice of the chunk's interval lists
+            v.intv_cap = seeds_of_chunk.cap;
+            v.intv = seeds_of_chunk.intv.as<Intv>() + at * seeds_of_chunk.cap;
+            v.intv_seed_off = seeds_of_chunk.intv_seed_off.as<int32_t>() + at * seeds_of_chunk.cap;
+            v.n_intv = seeds_of_chunk.n_intv.as<int32_t>() + at;
+            v.n_seeds = seeds_of_chunk.n_seeds.as<int32_t>() + at;
+            v.l_rep = seeds_of_chunk.l_rep.as<int32_t>() + at;
+            v.smem_scratch = nullptr; v.smem_groups = 0;
+            return v;
+        };
+        TileView tv = make_view();
         HIP_OK(hipMemsetAsync(ws.err.p, 0, 64, ws.stream));
         HIP_OK(hipMemsetAsync(ws.cnt.p, 0, sizeof(DevCounters), ws.stream));
         HIP_OK(hipMemsetAsync(ws.job_cnt.p, 0, 64, ws.stream));
-        TIMED(ws, K_SEED, launch_seed(ws.stream, ix->d, opt, tv));
         TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_seeds, tv.seed_off, T));
         int64_t n_occ = 0; int32_t err = 0; int32_t errv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIP_OK(hipMemcpyAsync(&n_occ, tv.seed_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
-        HIP_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
         HIP_OK(hipStreamSynchronize(ws.stream));
-        if (err & ERR_INTV_CAP) { intv_cap *= 2; intv_cap_scale *= 2; { std::lock_guard<std::mutex> lk(g_stats.mu); ++g_stats.s.n_retries; } continue; }
         if (n_occ > ws.seed_cap) {
             if (!ws.ensure_seeds(n_occ + n_occ / 4)) return false;
-            TileView t2 = ws.view();
-            t2.n_reads = T; t2.max_len = L; t2.read_id0 = tv.read_id0; t2.seq = tv.seq; t2.seq_off = tv.seq_off;
-            tv = t2;
+            tv = make_view();
         }
         TIMED(ws, K_SA, launch_sa(ws.stream, ix->d, opt, tv, n_occ));
         TIMED(ws, K_CHAIN, launch_chain(ws.stream, ix->d, opt, tv, ws.chain_store.as<Chain>()));
@@ -613,20 +682,72 @@ static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, b
     const char* env_s = getenv("BWAMEM_HIP_STREAMS");
     int n_workers = std::max(1, std::min<int>((int)specs.size(), env_s ? atoi(env_s) : 4));
     while ((int)ix->extra_ws.size() < n_workers - 1) ix->extra_ws.push_back(new Workspace());
+
+    // Seeding chunks: runs of consecutive tiles.  k_seed cannot finish before its slowest read has (one lane walks one
+    // read), so a launch over one tile spends much of its time in a thin tail; over a few million reads the queue keeps
+    // the lanes fed for most of the launch.  A seeding thread stays one chunk ahead of the tile workers (two interval
+    // stores); BWAMEM_HIP_SEED_AHEAD=0 serialises it behind the tiles (isolated kernel timings).
+    std::vector<SeedChunk> chunks;
+    {
+        const char* e = getenv("BWAMEM_HIP_SEED_CHUNK");
+        const uint32_t chunk_reads = e && atoi(e) > 0 ? (uint32_t)atoi(e) : 2097152u;
+        const char* eg = getenv("BWAMEM_HIP_SEED_GB");
+        const int64_t budget = (int64_t)(eg && atoi(eg) > 0 ? atoi(eg) : 16) << 30;     // per interval store
+        for (size_t i = 0; i < specs.size(); ++i) {
+            const int64_t n_new = chunks.empty() ? 0 : (int64_t)(specs[i].r1 - chunks.back().r0);
+            const int L_new = chunks.empty() ? 1 : std::max(chunks.back().L, specs[i].L);
+            if (chunks.empty() || n_new > (int64_t)chunk_reads || n_new * std::max(64, L_new + 8) * 36 > budget) {
+                SeedChunk c; c.r0 = specs[i].r0; c.tile0 = i; c.L = 1;
+                chunks.push_back(c);
+            }
+            SeedChunk& c = chunks.back();
+            c.r1 = specs[i].r1; c.tile1 = i + 1; c.L = std::max(c.L, specs[i].L); c.tiles_left = c.tile1 - c.tile0;
+        }
+    }
+    std::vector<size_t> chunk_of(specs.size());
+    for (size_t c = 0; c < chunks.size(); ++c) for (size_t i = chunks[c].tile0; i < chunks[c].tile1; ++i) chunk_of[i] = c;
+    const bool seed_ahead = !(getenv("BWAMEM_HIP_SEED_AHEAD") && atoi(getenv("BWAMEM_HIP_SEED_AHEAD")) == 0);
+    std::mutex mu;
+    std::condition_variable cv;
     std::atomic<size_t> next(0);
     std::atomic<bool> failed(false);
+    auto seeder = [&]() {
+        if (hipSetDevice(ix->device) != hipSuccess) { failed = true; cv.notify_all(); return; }
+        int intv_cap_scale = 1;
+        for (size_t c = 0; c < chunks.size() && !failed; ++c) {
+            {   // the store of chunk c was last used by chunk c-2
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] {
+                    if (failed) return true;
+                    for (size_t k = 0; k < c; ++k) if ((k + 2 <= c || !seed_ahead) && chunks[k].tiles_left != 0) return false;
+                    return true;
+                });
+            }
+            if (failed) break;
+            const bool ok = seed_chunk(ix, opt, b, chunks[c], ix->seed_store[c & 1], intv_cap_scale);
+            { std::lock_guard<std::mutex> lk(mu); chunks[c].state = ok ? 1 : -1; if (!ok) failed = true; }
+            cv.notify_all();
+        }
+    };
     auto worker = [&](int k) {
         Workspace& w = k == 0 ? ix->ws : *ix->extra_ws[k - 1];
-        if (hipSetDevice(ix->device) != hipSuccess) { failed = true; return; }
-        if (!w.stream && hipStreamCreate(&w.stream) != hipSuccess) { failed = true; return; }
-        int intv_cap_scale = 1, out_cap = 512;
+        if (hipSetDevice(ix->device) != hipSuccess) { failed = true; cv.notify_all(); return; }
+        if (!w.stream && hipStreamCreate(&w.stream) != hipSuccess) { failed = true; cv.notify_all(); return; }
+        int out_cap = 512;
         while (!failed) {
             size_t i = next++;
             if (i >= specs.size()) break;
-            if (!run_tile_se(ix, w, opt, b, read_id0, specs[i], b->tiles[i], intv_cap_scale, out_cap)) failed = true;
+            const size_t c = chunk_of[i];
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return failed || chunks[c].state != 0; }); }
+            if (failed) break;
+            if (!run_tile_se(ix, w, opt, b, read_id0, specs[i], b->tiles[i], ix->seed_store[c & 1], chunks[c].r0, out_cap)) failed = true;
+            { std::lock_guard<std::mutex> lk(mu); --chunks[c].tiles_left; }
+            cv.notify_all();
         }
+        cv.notify_all();
     };
     std::vector<std::thread> th;
+    th.emplace_back(seeder);
     for (int k = 1; k < n_workers; ++k) th.emplace_back(worker, k);
     worker(0);
     for (std::thread& t : th) t.join();

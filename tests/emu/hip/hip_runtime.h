@@ -105,6 +105,7 @@ static inline int emu_readlane(int v, int lane) { return __shfl(v, lane); }
 
 template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 static inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
+static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
 
 // ---- runtime API subset
 typedef int hipError_t;

@@ -79,6 +79,10 @@ def test_emu_seed_work_queue_and_spill(emu, oracle, small_genome, monkeypatch):
     seqs, img = small_genome
     reads = B.simulate_reads(seqs, 130, length=70, seed=21, sub=0.03, indel=0.004, n_rate=0.01, random_frac=0.1)
     reads += [b"ACGT" * 20, b"N" * 30, b"", b"A" * 18, b"ACGTN" * 20] * 4
+    # chimeras of six 40-base pieces: more long unique matches than the LDS list of pass-2 candidates holds
+    g = seqs[0][1] if isinstance(seqs[0], tuple) else seqs[0]
+    for k in range(3):
+        reads.append(b"".join(bytes(g[1000 * (7 * j + k + 1):1000 * (7 * j + k + 1) + 40]) for j in range(6)))
     monkeypatch.setenv("BWAMEM_HIP_SEED_WPC", "1")
     monkeypatch.setenv("BWAMEM_HIP_SEED_K", "3")
     _cmp(emu, oracle, img, reads)
