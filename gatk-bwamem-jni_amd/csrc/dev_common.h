@@ -220,10 +220,20 @@ DEV void score_lane(const ScoreTab& T, int q, uint32_t& p, int& n)
 DEV int score_at(uint32_t p, int n, int tb) { return tb < 4 ? (int)(int8_t)(p >> (tb << 3)) : n; }
 DEV int score_max(const MemOpt& opt) { int mx = 0; for (int k = 0; k < 25; ++k) mx = mx > opt.mat[k] ? mx : opt.mat[k]; return mx; }
 
+// (int)((double)x / e + k) as upstream writes its gap bounds, in integers: x / e + k = (x + k e) / e exactly, a double
+// quotient of two ints is nowhere near far enough from that to cross an integer, and both the cast and C division
+// truncate toward zero.  (A double division costs ~30 vector instructions on this hardware; e is 1 by default.)
+DEV int div_plus(int x, int e, int k)
+{
+    if (e == 1) return x + k;
+    if (e <= 0) return (int)((double)x / e + (double)k);
+    return (x + k * e) / e;
+}
+
 DEV int cal_max_gap(const MemOpt& opt, int qlen)
 {
-    int l_del = (int)((double)(qlen * opt.a - opt.o_del) / opt.e_del + 1.);
-    int l_ins = (int)((double)(qlen * opt.a - opt.o_ins) / opt.e_ins + 1.);
+    int l_del = div_plus(qlen * opt.a - opt.o_del, opt.e_del, 1);
+    int l_ins = div_plus(qlen * opt.a - opt.o_ins, opt.e_ins, 1);
     int l = l_del > l_ins ? l_del : l_ins;
     l = l > 1 ? l : 1;
     return l < opt.w << 1 ? l : opt.w << 1;

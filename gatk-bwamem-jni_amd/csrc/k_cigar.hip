@@ -17,24 +17,29 @@
 
 struct GLds { int32_t* eh_h; int32_t* eh_e; int32_t* tmpM; };
 
-// backtrack through the direction bytes (lane 0); ops come out end-to-start and are reversed in place
+// backtrack through the direction bytes (lane 0); ops come out end-to-start and are reversed in place.  The run being
+// built stays in registers: the CIGAR pool is global memory, and a read-modify-write per step would put a global
+// round trip on every one of the ~tlen steps.
 static __device__ int traceback(const uint8_t* z, int n_col, int w, int tlen, int qlen, int lane, uint32_t* cigar, int cig_cap, int& err)
 {
     int n = 0;
     if (lane == 0) {
         int which = 0, i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+        int cur_op = -1;
+        uint32_t cur_len = 0;
         bool ovf = false;
+#define TB_PUSH(OP, LEN) do { if ((OP) == cur_op) cur_len += (uint32_t)(LEN); else { \
+            if (cur_len) { if (n >= cig_cap) ovf = true; else cigar[n++] = cur_len << 4 | (uint32_t)cur_op; } cur_op = (OP); cur_len = (uint32_t)(LEN); } } while (0)
         while (i >= 0 && k >= 0 && !ovf) {
-            int op;
-            which = z[(int64_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
-            if (which == 0) { op = 0; --i; --k; }
-            else if (which == 1) { op = 2; --i; }
-            else { op = 1; --k; }
-            if (n == 0 || op != (int)(cigar[n - 1] & 0xf)) { if (n >= cig_cap) ovf = true; else cigar[n++] = 1u << 4 | (uint32_t)op; }
-            else cigar[n - 1] += 1u << 4;
+            which = z[i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+            if (which == 0) { TB_PUSH(0, 1); --i; --k; }
+            else if (which == 1) { TB_PUSH(2, 1); --i; }
+            else { TB_PUSH(1, 1); --k; }
         }
-        if (!ovf && i >= 0) { if (n == 0 || 2 != (int)(cigar[n - 1] & 0xf)) { if (n >= cig_cap) ovf = true; else cigar[n++] = (uint32_t)(i + 1) << 4 | 2; } else cigar[n - 1] += (uint32_t)(i + 1) << 4; }
-        if (!ovf && k >= 0) { if (n == 0 || 1 != (int)(cigar[n - 1] & 0xf)) { if (n >= cig_cap) ovf = true; else cigar[n++] = (uint32_t)(k + 1) << 4 | 1; } else cigar[n - 1] += (uint32_t)(k + 1) << 4; }
+        if (!ovf && i >= 0) TB_PUSH(2, i + 1);
+        if (!ovf && k >= 0) TB_PUSH(1, k + 1);
+        if (!ovf) TB_PUSH(-1, 0);                                 // flush the last run
+#undef TB_PUSH
         for (int a = 0; a < n >> 1; ++a) { uint32_t tmp = cigar[a]; cigar[a] = cigar[n - 1 - a]; cigar[n - 1 - a] = tmp; }
         if (ovf) { err |= ERR_CIGAR_CAP; n = 0; }
     }
@@ -194,8 +199,8 @@ __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView
         do {
             w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
             int w, max_gap, max_ins, max_del, min_w, d;                // band of bwa_gen_cigar2
-            max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
-            max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+            max_ins = div_plus(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins, opt.e_ins, 1);
+            max_del = div_plus(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del, opt.e_del, 1);
             max_gap = max_ins > max_del ? max_ins : max_del;
             max_gap = max_gap > 1 ? max_gap : 1;
             d = rlen - l_query; d = d < 0 ? -d : d;

@@ -55,10 +55,10 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
     }
     const int mx = score_max(opt);
     {   // clip the band by the longest affordable gap
-        max_ins = (int)((double)(qlen * mx + end_bonus - o_ins) / e_ins + 1.);
+        max_ins = div_plus(qlen * mx + end_bonus - o_ins, e_ins, 1);
         max_ins = max_ins > 1 ? max_ins : 1;
         w = w < max_ins ? w : max_ins;
-        max_del = (int)((double)(qlen * mx + end_bonus - o_del) / e_del + 1.);
+        max_del = div_plus(qlen * mx + end_bonus - o_del, e_del, 1);
         max_del = max_del > 1 ? max_del : 1;
         w = w < max_del ? w : max_del;
     }
@@ -219,10 +219,10 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
     }
     const int mx = score_max(opt);
     {
-        max_ins = (int)((double)(qlen * mx + end_bonus - o_ins) / e_ins + 1.);
+        max_ins = div_plus(qlen * mx + end_bonus - o_ins, e_ins, 1);
         max_ins = max_ins > 1 ? max_ins : 1;
         w = w < max_ins ? w : max_ins;
-        max_del = (int)((double)(qlen * mx + end_bonus - o_del) / e_del + 1.);
+        max_del = div_plus(qlen * mx + end_bonus - o_del, e_del, 1);
         max_del = max_del > 1 ? max_del : 1;
         w = w < max_del ? w : max_del;
     }

@@ -538,7 +538,15 @@ struct SeedChunk { uint32_t r0 = 0, r1 = 0; int L = 1; size_t tile0 = 0, tile1 =
 static bool seed_chunk(bwaidx_s* ix, const MemOpt& opt, bwamem_batch_s* b, const SeedChunk& ch, SeedStore& store, int& intv_cap_scale)
 {
     Workspace& sw = ix->seed_ws;
-    if (!sw.stream) HIP_OK(hipStreamCreate(&sw.stream));
+    if (!sw.stream) {
+        // the persistent seeding grid is gather-bound and needs only a few waves per CU: let the dispatcher place it first
+        // (highest stream priority) and fill the remaining wave slots with the tiles' arithmetic-bound kernels
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const char* e = getenv("BWAMEM_HIP_SEED_PRIO");
+        const int prio = e ? (atoi(e) > 0 ? hi : atoi(e) < 0 ? lo : 0) : hi;
+        HIP_OK(hipStreamCreateWithPriority(&sw.stream, hipStreamNonBlocking, prio));
+    }
     const int T = (int)(ch.r1 - ch.r0), L = ch.L;
     const int max_groups = 8192;                                 // upper bound on the persistent k_seed grid
     const int groups = std::min(max_groups, (T + 63) / 64);

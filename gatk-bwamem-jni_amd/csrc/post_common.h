@@ -77,6 +77,31 @@ struct SeqAcc {                  // query / target accessors with optional rever
 DEV int acc_q(const SeqAcc& A, int j) { return A.q[A.rev ? A.qlen - 1 - j : j]; }
 DEV int acc_t(const DevIndex& ix, const SeqAcc& A, int i) { return ref_base2(ix, A.t0 + (A.rev ? A.tlen - 1 - i : i)); }
 
+// The same accessors for the per-base loops of the one-lane-per-read kernels, through a one-word cache each: 16
+// reference bases or 4 query bases per global load instead of one (those loops are bound by the latency of their
+// dependent loads, not by arithmetic).
+struct SeqCache { int64_t pw; uint32_t pv; const uint32_t* qp; uint32_t qv; };
+DEV void seq_cache_init(SeqCache& c) { c.pw = -1; c.pv = 0; c.qp = 0; c.qv = 0; }
+DEV int pac_base_c(const DevIndex& ix, SeqCache& c, int64_t l)
+{
+    const int64_t w = l >> 4;
+    if (w != c.pw) { c.pw = w; c.pv = ((const uint32_t*)ix.pac)[w]; }
+    const int k = (int)(l & 15);
+    return (int)(c.pv >> (((k >> 2) << 3) + 6 - ((k & 3) << 1)) & 3u);
+}
+DEV int acc_t_c(const DevIndex& ix, const SeqAcc& A, SeqCache& c, int i)
+{
+    const int64_t p = A.t0 + (A.rev ? A.tlen - 1 - i : i);
+    return p < ix.l_pac ? pac_base_c(ix, c, p) : 3 - pac_base_c(ix, c, (ix.l_pac << 1) - 1 - p);
+}
+DEV int acc_q_c(const SeqAcc& A, SeqCache& c, int j)
+{
+    const uint8_t* a = A.q + (A.rev ? A.qlen - 1 - j : j);
+    const uint32_t* wp = (const uint32_t*)((uintptr_t)a & ~(uintptr_t)3);
+    if (wp != c.qp) { c.qp = wp; c.qv = *wp; }
+    return (int)(c.qv >> (((uintptr_t)a & 3) << 3) & 0xffu);
+}
+
 // ksw_global2: banded global alignment, optional traceback into S.cig[1..]
 DEV int global_dp(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const SeqAcc& A, int w, bool want_cigar, int* n_cigar_)
 {
@@ -152,19 +177,20 @@ DEV void cigar_nm_md(const DevIndex& ix, PostScratch& S, const SeqAcc& A, int n_
     int k, x, y, u, n_mm = 0, n_gap = 0;
     const char* int2base = fwd_strand ? "ACGTN" : "TGCAN";
     MdBuf md; md.s = S.md; md.cap = S.md_cap; md.l = 0; md.ovf = false;
+    SeqCache sc; seq_cache_init(sc);
     for (k = 0, x = y = u = 0; k < n_cig; ++k) {
         int op = cigar[k] & 0xf, len = (int)(cigar[k] >> 4);
         if (op == 0) {
             for (int i = 0; i < len; ++i) {
-                int tb = acc_t(ix, A, y + i);
-                if (acc_q(A, x + i) != tb) { md.putw(u); md.putc(int2base[tb]); ++n_mm; u = 0; }
+                int tb = acc_t_c(ix, A, sc, y + i);
+                if (acc_q_c(A, sc, x + i) != tb) { md.putw(u); md.putc(int2base[tb]); ++n_mm; u = 0; }
                 else ++u;
             }
             x += len; y += len;
         } else if (op == 2) {
             if (k > 0 && k < n_cig - 1) {            // not for a leading / trailing D
                 md.putw(u); md.putc('^');
-                for (int i = 0; i < len; ++i) md.putc(int2base[acc_t(ix, A, y + i)]);
+                for (int i = 0; i < len; ++i) md.putc(int2base[acc_t_c(ix, A, sc, y + i)]);
                 u = 0; n_gap += len;
             }
             y += len;
@@ -194,13 +220,19 @@ DEV bool gen_cigar2(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int w
     int n_cig = 0;
     if (l_query == re - rb && w_ == 0) {               // no gap: no DP
         int sc = 0;
-        for (int i = 0; i < l_query; ++i) sc += opt.mat[acc_t(ix, A, i) * 5 + acc_q(A, i)];
+        const ScoreTab ST = score_tab(opt);
+        SeqCache cc; seq_cache_init(cc);
+        for (int i = 0; i < l_query; ++i) {
+            uint32_t sp; int sn;
+            score_lane(ST, acc_q_c(A, cc, i), sp, sn);
+            sc += score_at(sp, sn, acc_t_c(ix, A, cc, i));
+        }
         *score = sc;
         if (want_cigar) { S.cig[1] = (uint32_t)l_query << 4; n_cig = 1; }
     } else {
         int w, max_gap, max_ins, max_del, min_w, d;
-        max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
-        max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+        max_ins = div_plus(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins, opt.e_ins, 1);
+        max_del = div_plus(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del, opt.e_del, 1);
         max_gap = max_ins > max_del ? max_ins : max_del;
         max_gap = max_gap > 1 ? max_gap : 1;
         d = rlen - l_query; d = d < 0 ? -d : d;
@@ -253,7 +285,7 @@ DEV int infer_bw(int l1, int l2, int score, int a, int q, int r)
 {
     int w, d;
     if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
-    w = (int)((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.);
+    w = div_plus((l1 < l2 ? l1 : l2) * a - score - q, r, 2);
     d = l1 - l2; d = d < 0 ? -d : d;
     if (w < d) w = d;
     return w;

@@ -11,7 +11,7 @@ run() { name=$1; shift
   rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_$name -o p -- /tmp/drive /tmp/prof.img /tmp/prof.req 1 > /tmp/pmc_$name.log 2>&1
   echo "== $name rc=$?"; tail -2 /tmp/pmc_$name.log
   f=$(ls /tmp/pmc_$name/*counter_collection.csv 2>/dev/null | head -1)
-  [ -n "$f" ] && { head -1 $f > $R/gpurun_out/pmc_$name.csv; grep -E 'k_(seed|extend|final_se|sa|chain)' $f >> $R/gpurun_out/pmc_$name.csv; wc -l $R/gpurun_out/pmc_$name.csv; }
+  [ -n "$f" ] && { head -1 $f > $R/gpurun_out/pmc_$name.csv; grep -E 'k_(seed|extend|final_se|sa|chain|gcigar)' $f >> $R/gpurun_out/pmc_$name.csv; wc -l $R/gpurun_out/pmc_$name.csv; }
 }
 run sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES
 run fetch FETCH_SIZE
