@@ -11,12 +11,6 @@ void launch_sa(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const Tile
 void launch_chain(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, Chain* chain_store);
 void launch_rescore(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 void launch_extend(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
-// extension in rounds (k_extend.hip): buffers sized by extend_rounds_bytes(n_reads, what), what = 0 states, 1 results, 2 tasks, 3 bin lists, 4 counters, 5 left-over list.
-// launch_extend_rounds synchronises the stream between rounds (it reads the task counts back).
-struct ExtRoundBufs { void* states; void* res; void* tasks; int32_t* bin_list; int32_t* counters; int32_t* left_list; };
-bool extend_rounds_supported(const MemOpt& opt, const TileView& tv);
-size_t extend_rounds_bytes(int n_reads, int what);
-hipError_t launch_extend_rounds(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, const ExtRoundBufs& B);
 void launch_post1(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 void launch_final_prep(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 void launch_gcigar(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, int n_jobs, const void* jobs, void* outs, uint32_t* cig_pool, int cig_cap,

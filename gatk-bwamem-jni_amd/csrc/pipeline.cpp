@@ -67,7 +67,6 @@ struct Workspace {
     DevBuf seeds, seed_rid, cseeds, chains, chain_store, n_chains, bt_nodes, srt, regs, n_regs;
     DevBuf out, out_len, out_off, post, err, cnt;
     DevBuf jobs, job_out, job_cig, job_cnt, zpool;   // single-end global-alignment jobs
-    DevBuf xr[6];                                     // extension in rounds (see ExtRoundBufs)
     int job_cap = 0, job_cig_cap = 0; size_t zpool_cap = 0;
     hipStream_t stream = nullptr;
     std::vector<Timed> timed;
@@ -97,7 +96,7 @@ struct Workspace {
     void release() {
         DevBuf* all[] = { &intv, &n_intv, &smem, &l_rep, &n_seeds, &seed_off, &intv_seed_off, &seeds, &seed_rid, &cseeds, &chains,
                           &chain_store, &n_chains, &bt_nodes, &srt, &regs, &n_regs, &out, &out_len, &out_off, &post, &err, &cnt,
-                          &jobs, &job_out, &job_cig, &job_cnt, &zpool, &xr[0], &xr[1], &xr[2], &xr[3], &xr[4], &xr[5] };
+                          &jobs, &job_out, &job_cig, &job_cnt, &zpool };
         for (DevBuf* b : all) b->release();
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     }
@@ -623,14 +622,7 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
         TIMED(ws, K_SA, launch_sa(ws.stream, ix->d, opt, tv, n_occ));
         TIMED(ws, K_CHAIN, launch_chain(ws.stream, ix->d, opt, tv, ws.chain_store.as<Chain>()));
         TIMED(ws, K_CHAIN, launch_rescore(ws.stream, ix->d, opt, tv));
-        if (extend_rounds_supported(opt, tv)) {
-            for (int k = 0; k < 6; ++k) if (!ws.xr[k].ensure(extend_rounds_bytes(T, k))) return false;
-            ExtRoundBufs xb; xb.states = ws.xr[0].p; xb.res = ws.xr[1].p; xb.tasks = ws.xr[2].p; xb.bin_list = ws.xr[3].as<int32_t>();
-            xb.counters = ws.xr[4].as<int32_t>(); xb.left_list = ws.xr[5].as<int32_t>();
-            hipError_t xe = hipSuccess;
-            TIMED(ws, K_EXTEND, xe = launch_extend_rounds(ws.stream, ix->d, opt, tv, xb));
-            HIP_OK(xe);
-        } else TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
+        TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
         if (getenv("BWAMEM_HIP_DUMP") && T <= 64) debug_dump(ws, tv, T);
         TIMED(ws, K_POST, launch_post1(ws.stream, ix->d, opt, tv));
         TIMED(ws, K_FINAL, launch_final_prep(ws.stream, ix->d, opt, tv));

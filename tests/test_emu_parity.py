@@ -86,15 +86,3 @@ def test_emu_seed_work_queue_and_spill(emu, oracle, small_genome, monkeypatch):
     monkeypatch.setenv("BWAMEM_HIP_SEED_WPC", "1")
     monkeypatch.setenv("BWAMEM_HIP_SEED_K", "3")
     _cmp(emu, oracle, img, reads)
-
-
-def test_emu_extension_rounds_leftovers(emu, oracle, small_genome, monkeypatch):
-    """extension in rounds: with a single round almost every read falls through to the wave-per-read kernel as a
-    left-over, with two rounds the reads that need exactly two extensions finish in the lane-per-task kernel"""
-    seqs, img = small_genome
-    reads = B.simulate_reads(seqs, 40, length=120, seed=33, sub=0.03, indel=0.006, random_frac=0.05)
-    for rounds in ("1", "2"):
-        monkeypatch.setenv("BWAMEM_HIP_EXT_ROUNDS", rounds)
-        _cmp(emu, oracle, img, reads)
-    monkeypatch.setenv("BWAMEM_HIP_EXTEND_WAVE", "1")                # and the wave-per-read kernel alone
-    _cmp(emu, oracle, img, reads)
