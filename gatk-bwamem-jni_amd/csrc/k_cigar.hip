@@ -174,11 +174,157 @@ static __device__ int global_wave_diag(const DevIndex& ix, const MemOpt& opt, co
     return score;
 }
 
+// Lane-per-job form for narrow bands (w <= WMAX: the regions with three or four mismatches, i.e. most jobs).  The wave
+// forms above spend ~100 vector instructions per row on a band that fills a third of the lanes.  Here every lane runs
+// the scalar recurrence for its own job with the whole band in registers: slot l of a lane holds column i - w + l of the
+// current row (one diagonal per slot, as in global_wave_diag), so H(i-1,j-1) is the slot's own value, E(i,j) the value
+// left by the next slot in the previous row, and F runs along the unrolled slots.  64 jobs per wavefront, ~30 vector
+// instructions per 64 cells.  Direction bits go to the HBM pool as one nibble per slot (20 bytes per row) and the
+// traceback of each lane reads them back.  Jobs it cannot take (wider band, retry with a doubled band needed) are left
+// marked for k_gcigar.
+struct GRowTab { uint32_t p[5]; int n[5]; };             // per target base: scores against query bases 0..3 (bytes), and against N
+DEV GRowTab g_row_tab(const MemOpt& opt)
+{
+    GRowTab T;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        T.p[t] = (uint32_t)(uint8_t)opt.mat[t * 5] | (uint32_t)(uint8_t)opt.mat[t * 5 + 1] << 8 | (uint32_t)(uint8_t)opt.mat[t * 5 + 2] << 16 | (uint32_t)(uint8_t)opt.mat[t * 5 + 3] << 24;
+        T.n[t] = opt.mat[t * 5 + 4];
+    }
+    return T;
+}
+
+template <int WMAX>
+__global__ void __launch_bounds__(64, 2) k_gcigar_lane(DevIndex ix, MemOpt opt, TileView tv, const DpJob* jobs, DpOut* outs, int n_jobs, uint32_t* cig_pool, int cig_cap,
+                                                    uint8_t* zpool, unsigned long long zpool_cap, unsigned long long* zpool_cur)
+{
+    constexpr int NS = 2 * WMAX + 1;                      // band slots
+    constexpr int ZW = (NS + 7) / 8;                      // dwords of direction nibbles per row
+    const int job = blockIdx.x * 64 + threadIdx.x;
+    if (job >= n_jobs) return;
+    const DpJob jb = jobs[job];
+    const AlnReg ar = tv.regs[tv.seed_off[jb.read] + jb.reg];
+    const uint8_t* query = tv.seq + tv.seq_off[jb.read];
+    SeqAcc A; A.q = query + ar.qb; A.qlen = ar.qe - ar.qb; A.rev = ar.rb >= ix.l_pac; A.t0 = ar.rb; A.tlen = (int)(ar.re - ar.rb);
+    const int qlen = A.qlen, tlen = A.tlen;
+    DpOut o; o.score = 0; o.n_cigar = -1;                 // -1: left for k_gcigar
+    const bool usable = !(qlen <= 0 || ar.rb >= ar.re || (ar.rb < ix.l_pac && ar.re > ix.l_pac) || ar.re > ix.l_pac << 1 || ar.rb < 0);
+    int w2 = first_w2(opt, ar), w = 0;
+    if (usable) {                                         // band of the first bwa_gen_cigar2 call
+        w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+        int max_ins = div_plus(((qlen + 1) >> 1) * opt.mat[0] - opt.o_ins, opt.e_ins, 1);
+        int max_del = div_plus(((qlen + 1) >> 1) * opt.mat[0] - opt.o_del, opt.e_del, 1);
+        int max_gap = max_ins > max_del ? max_ins : max_del;
+        max_gap = max_gap > 1 ? max_gap : 1;
+        int d = tlen - qlen; d = d < 0 ? -d : d;
+        w = (max_gap + d + 1) >> 1;
+        w = w < w2 ? w : w2;
+        const int min_w = d + 3;
+        w = w > min_w ? w : min_w;
+    }
+    const int l_end = qlen - 1 - (tlen - 1 - w);           // slot of the final cell
+    uint32_t* z = 0;
+    bool take = usable && w <= WMAX && l_end >= 0 && l_end <= 2 * w;
+    if (take) {
+        const unsigned long long need = ((unsigned long long)tlen * ZW * 4 + 63ull) & ~63ull;
+        const unsigned long long at = atomicAdd(zpool_cur, need);
+        if (at + need > zpool_cap) { atomicOr(tv.err, ERR_ZPOOL); take = false; }
+        else z = (uint32_t*)(zpool + at);
+    }
+    if (!take) { outs[job] = o; return; }
+
+    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const GRowTab RT = g_row_tab(opt);
+    SeqCache sc; seq_cache_init(sc);
+    int H[NS], E[NS], Q[NS];
+#pragma unroll
+    for (int l = 0; l < NS; ++l) {
+        const int j0 = l - w;
+        H[l] = j0 == 0 ? 0 : (j0 > 0 && j0 <= w ? -(o_ins + e_ins * j0) : MINUS_INF);   // upstream's initial eh[j].h
+        E[l] = MINUS_INF;
+        Q[l] = j0 >= 0 && j0 < qlen ? acc_q_c(A, sc, j0) : 4;
+    }
+    for (int i = 0; i < tlen; ++i) {
+        const int tb = acc_t_c(ix, A, sc, i);
+        const uint32_t R = tb == 0 ? RT.p[0] : tb == 1 ? RT.p[1] : tb == 2 ? RT.p[2] : tb == 3 ? RT.p[3] : RT.p[4];
+        const int Rn = tb == 0 ? RT.n[0] : tb == 1 ? RT.n[1] : tb == 2 ? RT.n[2] : tb == 3 ? RT.n[3] : RT.n[4];
+        const int c0 = i - w;                                // column of slot 0
+        const int hb = -(o_del + e_del * (i + 1));           // H(i,-1), the diagonal predecessor of column 0 in the next row
+        int f = MINUS_INF;
+        uint32_t zw[ZW];
+#pragma unroll
+        for (int k = 0; k < ZW; ++k) zw[k] = 0;
+#pragma unroll
+        for (int l = 0; l < NS; ++l) {
+            const int j = c0 + l;
+            const bool act = j >= 0 && j < qlen && l <= 2 * w;
+            const int q = Q[l];
+            const int s = q < 4 ? (int)(int8_t)(R >> (q << 3)) : Rn;
+            const int m = H[l] + s, e = E[l];
+            int d = m >= e ? 0 : 1;
+            int h = m >= e ? m : e;
+            d = h >= f ? d : 2;
+            h = h >= f ? h : f;
+            const int t = m - oe_del;
+            int e2 = e - e_del;
+            d |= e2 > t ? 4 : 0;
+            e2 = e2 > t ? e2 : t;
+            const int t2 = m - oe_ins;
+            int f2 = f - e_ins;
+            d |= f2 > t2 ? 8 : 0;
+            f2 = f2 > t2 ? f2 : t2;
+            H[l] = act ? h : (j == -1 ? hb : MINUS_INF);
+            if (l > 0) E[l - 1] = act ? e2 : MINUS_INF;      // E(i+1, j) is read by slot l-1 in the next row
+            f = act ? f2 : f;
+            zw[l >> 3] |= act ? (uint32_t)d << ((l & 7) << 2) : 0u;
+        }
+        E[NS - 1] = MINUS_INF;
+#pragma unroll
+        for (int k = 0; k < ZW; ++k) z[i * ZW + k] = zw[k];
+        const int inj = i + 1 - w + NS - 1;                  // query position entering the last slot
+        const int qin = inj >= 0 && inj < qlen ? acc_q_c(A, sc, inj) : 4;
+#pragma unroll
+        for (int l = 0; l + 1 < NS; ++l) Q[l] = Q[l + 1];
+        Q[NS - 1] = qin;
+    }
+    int score = MINUS_INF;
+#pragma unroll
+    for (int l = 0; l < NS; ++l) score = l == l_end ? H[l] : score;   // H(tlen-1, qlen-1)
+
+    // is this the CIGAR mem_reg2aln keeps, or does its loop retry with a doubled band?
+    if (!(w2 == opt.w << 2) && score < ar.truesc - opt.a) { outs[job] = o; return; }
+
+    uint32_t* cigar = cig_pool + (size_t)job * cig_cap;
+    int n = 0, cur_op = -1, which = 0, i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+    uint32_t cur_len = 0;
+    bool ovf = false;
+#define TB_PUSH(OP, LEN) do { if ((OP) == cur_op) cur_len += (uint32_t)(LEN); else { \
+        if (cur_len) { if (n >= cig_cap) ovf = true; else cigar[n++] = cur_len << 4 | (uint32_t)cur_op; } cur_op = (OP); cur_len = (uint32_t)(LEN); } } while (0)
+    while (i >= 0 && k >= 0 && !ovf) {
+        const int l = k - (i - w);
+        const uint32_t nib = z[i * ZW + (l >> 3)] >> ((l & 7) << 2) & 15u;
+        which = which == 0 ? (int)(nib & 3u) : which == 1 ? (int)(nib >> 2 & 1u) : (int)(nib >> 3 & 1u) << 1;
+        if (which == 0) { TB_PUSH(0, 1); --i; --k; }
+        else if (which == 1) { TB_PUSH(2, 1); --i; }
+        else { TB_PUSH(1, 1); --k; }
+    }
+    if (!ovf && i >= 0) TB_PUSH(2, i + 1);
+    if (!ovf && k >= 0) TB_PUSH(1, k + 1);
+    if (!ovf) TB_PUSH(-1, 0);
+#undef TB_PUSH
+    for (int a = 0; a < n >> 1; ++a) { uint32_t tmp = cigar[a]; cigar[a] = cigar[n - 1 - a]; cigar[n - 1 - a] = tmp; }
+    if (ovf) { atomicOr(tv.err, ERR_CIGAR_CAP); n = 0; }
+    o.score = score; o.n_cigar = n;
+    outs[job] = o;
+}
+
 __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView tv, const DpJob* jobs, DpOut* outs, uint32_t* cig_pool, int cig_cap,
                                                uint8_t* zpool, unsigned long long zpool_cap, unsigned long long* zpool_cur, int z_lds_cap)
 {
     HIP_DYNAMIC_SHARED(int32_t, smem)
     const int job = blockIdx.x, lane = threadIdx.x;
+    if (outs[job].n_cigar >= 0) return;                                // done by k_gcigar_lane
     const DpJob jb = jobs[job];
     const AlnReg ar = tv.regs[tv.seed_off[jb.read] + jb.reg];
     const uint8_t* query = tv.seq + tv.seq_off[jb.read];
@@ -241,5 +387,6 @@ void launch_gcigar(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const 
     { const char* e = getenv("BWAMEM_HIP_ZLDS"); if (e && atoi(e) >= 0) z_lds_cap = atoi(e); }
     size_t cap = (size_t)tv.max_len + 2;
     size_t shmem = 3 * cap * sizeof(int32_t) + ((cap + 15) & ~(size_t)15) + (size_t)z_lds_cap + 64;
+    hipLaunchKernelGGL(k_gcigar_lane<16>, dim3((n_jobs + 63) / 64), dim3(64), 0, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur);
     hipLaunchKernelGGL(k_gcigar, dim3(n_jobs), dim3(64), shmem, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap);
 }

@@ -592,7 +592,10 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
         if (++attempts > 8) { fprintf(stderr, "[bwamem_hip] tile could not be sized after 8 attempts\n"); return false; }
         if (!ws.ensure_reads(T, L, seeds_of_chunk.cap, out_cap, post_bytes_per_read(L, opt, false), false)) return false;
         if (!ws.ensure_seeds(std::max<int64_t>(ws.seed_cap, (int64_t)T * 16))) return false;
-        if (!ws.ensure_jobs(std::max(job_cap_hint, std::max(1024, T / 4)), 4 * L + 16, zpool_hint)) return false;
+        {   // the HBM pool also holds the direction nibbles of k_gcigar_lane: 20 bytes per target row of every job
+            const int jc = std::max(job_cap_hint, std::max(1024, T / 4));
+            if (!ws.ensure_jobs(jc, 4 * L + 16, std::max(zpool_hint, (size_t)jc * (size_t)(2 * L + 64) * 20 + ((size_t)64 << 20)))) return false;
+        }
         auto make_view = [&]() {
             TileView v = ws.view();
             v.n_reads = T; v.max_len = L; v.read_id0 = read_id0 + r0;
