@@ -54,12 +54,13 @@ enum {
 // ---- FM-index + reference resident in HBM ----
 // The image's occ/bwt array (one 64-byte line per 128 symbols with 4 x u64 counts) is
 // re-blocked once at openIndex into 32-byte blocks of 64 symbols: 16 bytes of counts + 4 x u32 of 16 symbols
-// each (MSB first).  The counts are the absolute numbers of C, G and T before the block, 40 bits each (A follows
+// each (MSB first).  The counts are the absolute numbers of C, G and T before the block, 40 bits each: three low words plus one word of
+// high bytes, so that unpacking costs three bit-field extracts (A follows
 // from the block position: 64*b - C - G - T).  A rank query then needs two 16-byte lane loads instead of four and
 // popcounts at most 4 words instead of 8.  The seeding kernel is bound by per-lane vector-memory requests, so
 // this halves its cost.  40-bit counts cover texts up to 2^40 symbols.
 struct DevIndex {
-    const uint4* occ;          // 2 x uint4 per 64-symbol block: {C:40 | G:40 | T:40 packed}, {sym[4]}
+    const uint4* occ;          // 2 x uint4 per 64-symbol block: {C, G, T low words, high bytes}, {sym[4]}
     const uint64_t* sa;        // sampled every sa_intv ranks; sa[0] = (u64)-1
     const uint8_t*  pac;       // 2 bit/base, first base in the two MSBs
     const int64_t*  ann_offset;

@@ -21,13 +21,13 @@ DEV void cnt_word(uint32_t x, int n, uint32_t& c1, uint32_t& c2, uint32_t& c3)
     c1 += __popc(~hi & lo);
 }
 
-// absolute counts of A,C,G,T before block b from its packed 16-byte count word
+// absolute counts of A,C,G,T before block b from its 16-byte count word: the low 32 bits of C, G, T in x, y, z and
+// bits 32..39 of each in the three low bytes of w (a 64-bit value is a register pair, so the low halves need no work)
 DEV void occ_unpack(const uint4& c, uint64_t b, uint64_t& a0, uint64_t& a1, uint64_t& a2, uint64_t& a3)
 {
-    const uint64_t lo = (uint64_t)c.y << 32 | c.x, hi = (uint64_t)c.w << 32 | c.z;
-    a1 = lo & 0xffffffffffull;
-    a2 = (lo >> 40) | ((hi & 0xffff) << 24);
-    a3 = (hi >> 16) & 0xffffffffffull;
+    a1 = (uint64_t)(c.w & 0xffu) << 32 | c.x;
+    a2 = (uint64_t)(c.w >> 8 & 0xffu) << 32 | c.y;
+    a3 = (uint64_t)(c.w >> 16 & 0xffu) << 32 | c.z;
     a0 = (b << 6) - a1 - a2 - a3;
 }
 

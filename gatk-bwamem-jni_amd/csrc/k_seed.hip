@@ -12,26 +12,38 @@
 
 // The symbol words and packed counts of the two blocks an extension needs are requested together (four 16-byte
 // lane loads in flight), whether or not the two ranks share a block: one code path for the whole wave, and a repeated
-// block is a cache hit.  Same arithmetic as occ4 (dev_common.h).
+// block is a cache hit.  Same arithmetic as occ4 (dev_common.h) for ranks k, l >= 0 -- the seeding walk never asks for
+// rank -1: every interval it extends starts at 1 or later (set by L2[c] + 1, kept by the extension formulas).
+DEV uint32_t mask16(int n)                                  // bit-plane mask of the first n (clamped to 0..16) symbols of a word
+{
+    n = n < 0 ? 0 : n > 16 ? 16 : n;
+    return (uint32_t)(0x5555555500000000ull >> (n << 1));
+}
+DEV void cnt_word_m(uint32_t x, uint32_t m, uint32_t& c1, uint32_t& c2, uint32_t& c3)
+{
+    const uint32_t lo = x & m, hi = (x >> 1) & m;
+    c3 += __popc(hi & lo);
+    c2 += __popc(hi & ~lo);
+    c1 += __popc(~hi & lo);
+}
 DEV void occ4_two(const DevIndex& ix, uint64_t k, uint64_t l, uint64_t tk[4], uint64_t tl[4])
 {
-    const bool zk = k == (uint64_t)-1, zl = l == (uint64_t)-1;
-    const uint64_t kk = zk ? 0 : k - (k >= ix.primary), ll = zl ? 0 : l - (l >= ix.primary);
+    const uint64_t kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
     const uint64_t bk = kk >> 6, bl = ll >> 6;
     const uint4* pk = ix.occ + 2 * bk;
     const uint4* pl = ix.occ + 2 * bl;
     const uint4 ck = pk[0], sk = pk[1], cl = pl[0], sl = pl[1];
     const int nk = (int)(kk & 63) + 1, nl = (int)(ll & 63) + 1;
     uint32_t a1 = 0, a2 = 0, a3 = 0, b1 = 0, b2 = 0, b3 = 0;
-    cnt_word(sk.x, nk, a1, a2, a3);       cnt_word(sl.x, nl, b1, b2, b3);
-    cnt_word(sk.y, nk - 16, a1, a2, a3);  cnt_word(sl.y, nl - 16, b1, b2, b3);
-    cnt_word(sk.z, nk - 32, a1, a2, a3);  cnt_word(sl.z, nl - 32, b1, b2, b3);
-    cnt_word(sk.w, nk - 48, a1, a2, a3);  cnt_word(sl.w, nl - 48, b1, b2, b3);
+    cnt_word_m(sk.x, mask16(nk), a1, a2, a3);       cnt_word_m(sl.x, mask16(nl), b1, b2, b3);
+    cnt_word_m(sk.y, mask16(nk - 16), a1, a2, a3);  cnt_word_m(sl.y, mask16(nl - 16), b1, b2, b3);
+    cnt_word_m(sk.z, mask16(nk - 32), a1, a2, a3);  cnt_word_m(sl.z, mask16(nl - 32), b1, b2, b3);
+    cnt_word_m(sk.w, mask16(nk - 48), a1, a2, a3);  cnt_word_m(sl.w, mask16(nl - 48), b1, b2, b3);
     uint64_t c0, c1, c2, c3, d0, d1, d2, d3;
     occ_unpack(ck, bk, c0, c1, c2, c3);
     occ_unpack(cl, bl, d0, d1, d2, d3);
-    tk[0] = zk ? 0 : c0 + (uint32_t)(nk - (int)(a1 + a2 + a3)); tk[1] = zk ? 0 : c1 + a1; tk[2] = zk ? 0 : c2 + a2; tk[3] = zk ? 0 : c3 + a3;
-    tl[0] = zl ? 0 : d0 + (uint32_t)(nl - (int)(b1 + b2 + b3)); tl[1] = zl ? 0 : d1 + b1; tl[2] = zl ? 0 : d2 + b2; tl[3] = zl ? 0 : d3 + b3;
+    tk[0] = c0 + (uint32_t)(nk - (int)(a1 + a2 + a3)); tk[1] = c1 + a1; tk[2] = c2 + a2; tk[3] = c3 + a3;
+    tl[0] = d0 + (uint32_t)(nl - (int)(b1 + b2 + b3)); tl[1] = d1 + b1; tl[2] = d2 + b2; tl[3] = d3 + b3;
 }
 
 // bwt_extend for one symbol, both directions through one code path (cf. extend_one in dev_common.h; this form always
@@ -143,16 +155,16 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
     bool any = false, ovf = false, exhausted = false, el_ok = true;
     const uint8_t* qg = tv.seq;
     Intv* mem = tv.intv;
-    uint32_t n_ext = 0, ext0 = 0;                        // ext0: n_ext when the current read was claimed (BWAMEM_HIP_SEEDSTAT statistics)
+    uint32_t n_ext = 0;
 
 #define QAT(p) (LDSQ ? (int)(sq[((p) >> 3) * 64] >> (((p) & 7) << 2) & 15u) : (int)qg[(p)])
-#define FINISH() do { tv.n_intv[r] = ovf ? 0 : mem_n; if (ovf) atomicOr(tv.err, ERR_INTV_CAP); st = S_IDLE; \
-        if (tv.debug & 4) { const int d_ = (int)(n_ext - ext0); atomicMax(tv.err + 9, d_); atomicAdd(tv.err + 10 + (d_ < 1000 ? 0 : d_ < 2000 ? 1 : d_ < 4000 ? 2 : d_ < 8000 ? 3 : d_ < 16000 ? 4 : 5), 1); } } while (0)
+#define FINISH() do { fin = true; st = S_IDLE; } while (0)       // the read's result is stored once, at the end of the iteration
 #define MEM_PUSH(X0, SZ, INFO) do { if (mem_n >= tv.intv_cap) ovf = true; else { Intv v_; v_.x0 = (X0); v_.x1 = 0; v_.size = (SZ); v_.info = (INFO); mem[mem_n++] = v_; } } while (0)
 #define PUSH_IK() do { if (V.push(nf, ik0, iks, end)) ++nf; else ovf = true; } while (0)
 #define BEGIN_BWD() do { ret = end; lo = 0; rd = wr = nf - 1; i = sx - 1; c = i >= 0 ? QAT(i) : 4; c = c < 4 ? c : -1; st = S_BWD; } while (0)
 
     for (;;) {
+        bool fin = false;
         // ---- work queue: idle lanes claim the next reads of the tile, the wave stages them in LDS together
         const unsigned long long idle = __ballot(st == S_IDLE);
         if (idle != 0ull && !exhausted && (__popcll(idle) >= refill_min || idle == ~0ull)) {
@@ -170,7 +182,7 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
                     len = (int)(tv.seq_off[r + 1] - off - 1);
                     qg = tv.seq + off;
                     mem = tv.intv + (size_t)r * tv.intv_cap;
-                    mem_n = 0; ovf = false; pass = 1; x = 0; st = S_NEXT; n_el = 0; el_ok = true; ext0 = n_ext;
+                    mem_n = 0; ovf = false; pass = 1; x = 0; st = S_NEXT; n_el = 0; el_ok = true;
                 }
             }
             if (LDSQ) {
@@ -183,19 +195,24 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
                     const int nb = (int)(tv.seq_off[rr + 1] - off) - 1;
                     for (int k = lane; k * 8 < nb; k += 64) {           // lane k packs bases 8k .. 8k+7 of the read claimed by lane l
                         uint32_t wd = 0;
-                        for (int b = 0; b < 8; ++b) { const int pos = k * 8 + b; wd |= (uint32_t)(pos < nb ? tv.seq[off + pos] & 15 : 4) << (b << 2); }
+                        uint32_t by[8];
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) { const int pos = k * 8 + b; by[b] = tv.seq[off + (pos < nb ? pos : nb)]; }   // eight independent loads (nb: the terminator)
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) wd |= (k * 8 + b < nb ? by[b] & 15u : 4u) << (b << 2);
                         sq[k * 64 + (l - lane)] = wd;
                     }
                 }
                 __syncthreads();
             }
-            if (fresh && len < min_seed_len) FINISH();
+            if (fresh && len < min_seed_len) { tv.n_intv[r] = 0; st = S_IDLE; }      // too short to seed
         }
         if (__ballot(st != S_IDLE) == 0ull) break;
 
         // ---- between two searches: next SMEM start (pass 1), next interval to re-seed (pass 2), next greedy seed (pass 3)
         if (st == S_NEXT) {
             int nx = -1;
+            bool p3 = false;
             uint64_t nmin = 1;
             if (pass == 1) {
                 if (x >= len) { pass = 2; old_n = mem_n; k2 = 0; }
@@ -224,16 +241,17 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
             } else {
                 if (x >= len) FINISH();
                 else if (QAT(x) > 3) ++x;
-                else {
-                    const int b = QAT(x);
-                    ik0 = ix.L2[b] + 1; iks = ix.L2[b + 1] - ix.L2[b]; ik1 = ix.L2[3 - b] + 1;
-                    sx = x; i = x + 1; st = S_P3;
-                }
+                else { nx = x; p3 = true; }
             }
-            if (nx >= 0) {                                          // enter bwt_smem1(nx, nmin)
+            if (nx >= 0) {                                          // enter bwt_smem1(nx, nmin) or bwt_seed_strategy1(nx): the interval of one base
                 const int b = QAT(nx);
-                ik0 = ix.L2[b] + 1; iks = ix.L2[b + 1] - ix.L2[b]; ik1 = ix.L2[3 - b] + 1;
-                sx = nx; min_intv = nmin; end = sx + 1; i = sx + 1; nf = 0; any = false; st = S_FWD;
+                const uint64_t lb = b == 0 ? ix.L2[0] : b == 1 ? ix.L2[1] : b == 2 ? ix.L2[2] : ix.L2[3];
+                const uint64_t lb1 = b == 0 ? ix.L2[1] : b == 1 ? ix.L2[2] : b == 2 ? ix.L2[3] : ix.L2[4];
+                const uint64_t lc = b == 0 ? ix.L2[3] : b == 1 ? ix.L2[2] : b == 2 ? ix.L2[1] : ix.L2[0];
+                ik0 = lb + 1; iks = lb1 - lb; ik1 = lc + 1;
+                sx = nx; i = sx + 1;
+                if (p3) st = S_P3;
+                else { min_intv = nmin; end = sx + 1; nf = 0; any = false; st = S_FWD; }
             }
         }
 
@@ -241,13 +259,12 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
         bool need = false, bw = false, back = false;
         int rc = 0, pend = 0;
         uint64_t r0 = 0, r1 = 0, rs = 0;
+        bool fwd_end = false;                                       // forward phase stopped by the read's end or an ambiguous base
         if (st == S_FWD || st == S_P3) {
             const int cq = i < len ? QAT(i) : 4;
             if (cq < 4) { need = true; rc = 3 - cq; r0 = ik0; r1 = ik1; rs = iks; }
-            else if (st == S_FWD) {                                 // end of the read or an ambiguous base: forward phase over
-                PUSH_IK();
-                if (ovf) FINISH(); else BEGIN_BWD();
-            } else { x = i < len ? i + 1 : len; st = S_NEXT; }      // bwt_seed_strategy1 found nothing from sx
+            else if (st == S_FWD) fwd_end = true;
+            else { x = i < len ? i + 1 : len; st = S_NEXT; }        // bwt_seed_strategy1 found nothing from sx
         }
         if (st == S_BWD) {
             V.get(rd, nf, r0, rs, pend);
@@ -256,7 +273,8 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
         }
 
         // ---- one interval extension per lane, issued by the whole wave together
-        uint64_t o0 = 0, o1 = 0, os = 0;
+        uint64_t o0 = 0, o1 = 0, os = 0, em0 = 0, ems = 0, emi = 0;
+        bool emit = false;
         if (need) { extend_sm(ix, r0, r1, rs, rc, back, o0, o1, os); ++n_ext; }
 
         // ---- consume the result
@@ -265,7 +283,7 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
                 if (wr == nf - 1 && (!any || (uint64_t)(i + 1) < last_start)) {
                     any = true; last_start = (uint64_t)(i + 1);
                     if (pend - (i + 1) >= min_seed_len) {
-                        MEM_PUSH(r0, rs, (uint64_t)(i + 1) << 32 | (uint32_t)pend);
+                        emit = true; em0 = r0; ems = rs; emi = (uint64_t)(i + 1) << 32 | (uint32_t)pend;
                         // pass 2 re-seeds long matches with few occurrences from their middle: remember those as they
                         // are found, so that pass 2 does not have to read the list back from global memory
                         if (pass == 1 && pend - (i + 1) >= split_len && rs <= (uint64_t)(int64_t)opt.split_width) {
@@ -283,21 +301,23 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
                 if (wr == nf - 1) { if (pass == 1) x = ret; else ++k2; st = S_NEXT; }
                 else { lo = wr + 1; rd = wr = nf - 1; --i; c = i >= 0 ? QAT(i) : 4; c = c < 4 ? c : -1; }
             }
-            if (ovf) FINISH();
-        } else if (need) {
-            if (st == S_FWD) {
-                bool stop = false;
-                if (os != iks) { PUSH_IK(); stop = os < min_intv; }
-                if (ovf) FINISH();
-                else if (stop) BEGIN_BWD();
-                else { ik0 = o0; ik1 = o1; iks = os; end = i + 1; ++i; }
-            } else {                                                // S_P3
-                if (os < max_intv3 && i - sx >= min_seed_len) {
-                    if (os > 0) MEM_PUSH(o0, os, (uint64_t)sx << 32 | (uint32_t)(i + 1));
-                    x = i + 1; st = S_NEXT;
-                    if (ovf) FINISH();
-                } else { ik0 = o0; ik1 = o1; iks = os; ++i; }
-            }
+        } else if (st == S_FWD && (need || fwd_end)) {              // upstream pushes the interval whenever its size is about to change
+            const bool push = fwd_end || os != iks;
+            const bool stop = fwd_end || (push && os < min_intv);
+            if (push) PUSH_IK();
+            if (stop) BEGIN_BWD();                                  // (moot if the push overflowed: the read is abandoned below)
+            else { ik0 = o0; ik1 = o1; iks = os; end = i + 1; ++i; }
+        } else if (need) {                                          // S_P3
+            if (os < max_intv3 && i - sx >= min_seed_len) {
+                if (os > 0) { emit = true; em0 = o0; ems = os; emi = (uint64_t)sx << 32 | (uint32_t)(i + 1); }
+                x = i + 1; st = S_NEXT;
+            } else { ik0 = o0; ik1 = o1; iks = os; ++i; }
+        }
+        if (emit) MEM_PUSH(em0, ems, emi);                          // one store site for both kinds of match
+        if (ovf) FINISH();
+        if (fin) {                                                  // read r is complete (or ran out of room)
+            tv.n_intv[r] = ovf ? 0 : mem_n;
+            if (ovf) atomicOr(tv.err, ERR_INTV_CAP);
         }
     }
 #undef QAT
@@ -420,9 +440,9 @@ __global__ void k_build_occ64(const uint32_t* bwt, uint64_t n_blocks, uint4* occ
     uint32_t c1 = 0, c2 = 0, c3 = 0;
     if (b & 1) for (int i = 0; i < 4; ++i) cnt_word(blk[8 + i], 16, c1, c2, c3);   // first half of the source block
     const uint64_t C = cnt[1] + c1, G = cnt[2] + c2, T = cnt[3] + c3;
-    const uint64_t lo = (C & 0xffffffffffull) | (G << 40), hi = ((G >> 24) & 0xffff) | ((T & 0xffffffffffull) << 16);
     uint4 c, s;
-    c.x = (uint32_t)lo; c.y = (uint32_t)(lo >> 32); c.z = (uint32_t)hi; c.w = (uint32_t)(hi >> 32);
+    c.x = (uint32_t)C; c.y = (uint32_t)G; c.z = (uint32_t)T;
+    c.w = (uint32_t)(C >> 32 & 0xff) | (uint32_t)(G >> 32 & 0xff) << 8 | (uint32_t)(T >> 32 & 0xff) << 16;
     s.x = sym[0]; s.y = sym[1]; s.z = sym[2]; s.w = sym[3];
     occ[2 * b] = c; occ[2 * b + 1] = s;
 }

@@ -561,7 +561,6 @@ static bool seed_chunk(bwaidx_s* ix, const MemOpt& opt, bwamem_batch_s* b, const
         tv.intv_seed_off = store.intv_seed_off.as<int32_t>(); tv.n_seeds = store.n_seeds.as<int32_t>(); tv.l_rep = store.l_rep.as<int32_t>();
         tv.smem_scratch = sw.smem.as<Intv>(); tv.smem_cap = L + 2; tv.smem_groups = groups;
         tv.err = sw.err.as<int32_t>(); tv.cnt = sw.cnt.as<DevCounters>();
-        tv.debug = getenv("BWAMEM_HIP_SEEDSTAT") ? 4 : 0;          // per-read extension-count statistics (diagnostics)
         HIP_OK(hipMemsetAsync(sw.err.p, 0, 64, sw.stream));
         HIP_OK(hipMemsetAsync(sw.cnt.p, 0, sizeof(DevCounters), sw.stream));
         TIMED(sw, K_SEED, launch_seed(sw.stream, ix->d, opt, tv));
@@ -570,8 +569,6 @@ static bool seed_chunk(bwaidx_s* ix, const MemOpt& opt, bwamem_batch_s* b, const
         HIP_OK(hipMemcpyAsync(&hc, tv.cnt, sizeof hc, hipMemcpyDeviceToHost, sw.stream));
         HIP_OK(hipStreamSynchronize(sw.stream));
         timed_collect(sw);
-        if (tv.debug & 4)
-            fprintf(stderr, "[bwamem_hip] k_seed chunk of %d reads: max extensions/read %d; reads with <1k %d <2k %d <4k %d <8k %d <16k %d more %d\n", T, h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
         if (h[0] & ERR_INTV_CAP) { intv_cap_scale *= 2; { std::lock_guard<std::mutex> lk(g_stats.mu); ++g_stats.s.n_retries; } continue; }
         { std::lock_guard<std::mutex> lk(g_stats.mu); g_stats.s.n_ext += hc.n_ext; }
         return true;
