@@ -201,7 +201,7 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
     const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     int i, beg, end, max, max_i, max_j, max_ins, max_del, max_ie, gscore, max_off;
-    int ehh[C], ehe[C], scn[C];
+    int ehh[C], ehe[C], scn[C], je[C], jm1e[C];
     uint32_t scp[C];
     const ScoreTab ST = score_tab(opt);
     if (h0 < 0) h0 = 0;
@@ -216,6 +216,7 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
         }
         ehh[t] = v; ehe[t] = 0;
         score_lane(ST, j < qlen ? query[q0 + qstep * j] : 4, scp[t], scn[t]);
+        je[t] = j * e_ins; jm1e[t] = (j - 1) * e_ins;
     }
     const int mx = score_max(opt);
     {
@@ -232,15 +233,15 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
     for (i = 0; i < tlen; ++i) {
         if ((i & 63) == 0) { int ii = i + lane; tch = ii < tlen ? ref_base2(ix, t0 + (int64_t)tstep * ii) : 4; }
         const int tb = wave_readlane(tch, i & 63);
-        int m = 0, mj = -1, h1, h1i;
+        int m, mj, h1, h1i;
         if (beg < i - w) beg = i - w;
         if (end > i + w + 1) end = i + w + 1;
         if (end > qlen) end = qlen;
         if (beg == 0) { h1i = h0 - (o_del + e_del * (i + 1)); if (h1i < 0) h1i = 0; }
         else h1i = 0;
         h1 = h1i;
-        int hnew[C], enew[C];
-        int fcarry = NEG_INF_I32, prev_last = 0;
+        const int pos1 = end > beg ? beg : end;            // the column whose eh.h becomes the first-column value
+        int fcarry = NEG_INF_I32, prev_last = -1, best = -1;
 #pragma unroll
         for (int t = 0; t < C; ++t) {
             const int c0 = t * WAVE, j = c0 + lane;
@@ -249,41 +250,36 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
             const int sc = score_at(scp[t], scn[t], tb);
             const int M = act && Mp ? Mp + sc : 0;
             int tt = M - oe_ins; tt = tt > 0 ? tt : 0;
-            const int U = act ? tt + j * e_ins : NEG_INF_I32;
+            const int U = act ? tt + je[t] : NEG_INF_I32;
             const int P = dpp_prefix_max(U, NEG_INF_I32);
             const int Pex = dpp_shr1(P, NEG_INF_I32);
-            int f = fcarry - (j - c0) * e_ins;
-            { int g = Pex - (j - 1) * e_ins; f = f > g ? f : g; }
+            // F(i,j) = max over earlier columns k of (tt_k - (j-1-k) e_ins): never negative; fcarry brings in the earlier chunks
+            int f = Pex - jm1e[t];
+            if (t > 0) { const int fc = fcarry - (j - c0) * e_ins; f = f > fc ? f : fc; }
             if (j == beg) f = 0;
             int h = M > e ? M : e;
             h = h > f ? h : f;
             if (!act) h = -1;
-            const int mc = wave_readlane(dpp_prefix_max(h, -1), 63);
-            const unsigned long long bal = wave_ballot(act && h == mc);
-            if (bal && mc >= m) { m = mc; mj = c0 + 63 - __clzll((long long)bal); }
-            {
+            // row maximum with the last column that attains it: one scan over (h, column) keys; later chunks win ties
+            const int mk = wave_readlane(dpp_prefix_max(act ? h << 8 | j : -1, -1), 63);
+            best = mk >= best ? mk : best;
+            if (t + 1 < C) {
                 const int Plast = wave_readlane(P, 63);
                 const int f1 = fcarry - WAVE * e_ins, f2 = Plast - (c0 + 63) * e_ins;
                 fcarry = f1 > f2 ? f1 : f2;
             }
             int t2 = M - oe_del; t2 = t2 > 0 ? t2 : 0;
             int en = e - e_del; en = en > t2 ? en : t2;
-            hnew[t] = h; enew[t] = en;
-            // h of column end-1 (needed below) lives in this chunk?
             if (end > beg && ((end - 1) >> 6) == t) h1 = wave_readlane(h, (end - 1) & 63);
+            // in-place row update: eh[pos1].h = h1i, eh[j+1].h = H(i,j) for the live columns, eh[j].e = E(i+1,j), eh[end].e = 0.
+            // h is -1 outside the live columns, so "the column to the left was live" reads off the shifted value
+            const int hsh = dpp_shr1(h, prev_last);
+            if (t + 1 < C) prev_last = wave_readlane(h, 63);
+            ehh[t] = j == pos1 ? h1i : hsh >= 0 ? hsh : ehh[t];
+            ehe[t] = act ? en : j == end ? 0 : ehe[t];
         }
-#pragma unroll
-        for (int t = 0; t < C; ++t) {                      // in-place row update: eh[beg].h = h1i, eh[j+1].h = H(i,j), eh[end].e = 0
-            const int j = t * WAVE + lane;
-            const int hsh = dpp_shr1(hnew[t], prev_last);
-            prev_last = wave_readlane(hnew[t], 63);
-            if (end > beg) {
-                if (j == beg) ehh[t] = h1i;
-                else if (j > beg && j <= end) ehh[t] = hsh;
-                if (j >= beg && j < end) ehe[t] = enew[t];
-                else if (j == end) ehe[t] = 0;
-            } else if (j == end) { ehh[t] = h1i; ehe[t] = 0; }
-        }
+        m = best < 0 ? 0 : best >> 8;
+        mj = best < 0 ? -1 : best & 255;
         if (end > beg) n_cells += (unsigned long long)(end - beg);
         {
             const int jafter = end > beg ? end : beg;
