@@ -250,6 +250,17 @@ def main():
         alg_bytes = 64.0 * st.n_ext / n_launch
         avg_s = st.ms_seed * 1e-3 / n_launch
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        # HBM traffic of the same kernel: PMC counters cannot be read from inside this process, so the per-extension
+        # FETCH_SIZE measured by tests/gpu_units/pmc_seed.sh on this workload (committed summary, see profiles/README.md)
+        # is scaled to this launch's extension count
+        traffic, traffic_note = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_k_seed.json")) as f:
+                pmc = json.load(f)
+            traffic = pmc["fetch_bytes_per_ext"] * st.n_ext / n_launch
+            traffic_note = pmc.get("note")
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "150bp reads aligned/sec vs GRCh38-scale reference (1/2/4/8 MI355X)", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -258,7 +269,7 @@ def main():
                        "reads_per_gpu": R, "read_len": L, "genome_bp": args.genome_bp, "index_build_s": round(t_index, 1), "response_bytes": result_bytes,
                        "parallelism": "read-sharded x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "measured_in": "extra untimed step with nothing else on the GPU: one tile in flight, seeding chunks not overlapped (see DESIGN.md section 5)", "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": int(st.n_launch_seed),
+                         "traffic": traffic, "traffic_source": traffic_note, "measured_in": "extra untimed step with nothing else on the GPU: one tile in flight, seeding chunks not overlapped (see DESIGN.md section 5)", "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": int(st.n_launch_seed),
                          "n_ext_per_read": st.n_ext / max(1, st.n_reads)},
             "kernel_ms_isolated_pass": {k: round(v, 2) for k, v in kern.items()},
             "tiles_in_flight_timed": int(os.environ.get("BWAMEM_HIP_STREAMS", "4")),

@@ -201,7 +201,7 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
     const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     int i, beg, end, max, max_i, max_j, max_ins, max_del, max_ie, gscore, max_off;
-    int ehh[C], ehe[C], scn[C], je[C], jm1e[C];
+    int ehh[C], ehe[C], je[C], jm1e[C];
     uint32_t scp[C];
     const ScoreTab ST = score_tab(opt);
     if (h0 < 0) h0 = 0;
@@ -215,7 +215,7 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
             if (j == 1 || vj + e_ins > e_ins) v = vj;
         }
         ehh[t] = v; ehe[t] = 0;
-        score_lane(ST, j < qlen ? query[q0 + qstep * j] : 4, scp[t], scn[t]);
+        { int sn; score_lane(ST, j < qlen ? query[q0 + qstep * j] : 4, scp[t], sn); }
         je[t] = j * e_ins; jm1e[t] = (j - 1) * e_ins;
     }
     const int mx = score_max(opt);
@@ -247,7 +247,7 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
             const int c0 = t * WAVE, j = c0 + lane;
             const bool act = j >= beg && j < end;
             const int Mp = ehh[t], e = ehe[t];
-            const int sc = score_at(scp[t], scn[t], tb);
+            const int sc = (int)(int8_t)(scp[t] >> (tb << 3));   // tb is a reference base (0..3): rows past the target are never computed
             const int M = act && Mp ? Mp + sc : 0;
             int tt = M - oe_ins; tt = tt > 0 ? tt : 0;
             const int U = act ? tt + je[t] : NEG_INF_I32;
@@ -261,7 +261,7 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
             h = h > f ? h : f;
             if (!act) h = -1;
             // row maximum with the last column that attains it: one scan over (h, column) keys; later chunks win ties
-            const int mk = wave_readlane(dpp_prefix_max(act ? h << 8 | j : -1, -1), 63);
+            const int mk = wave_readlane(dpp_prefix_max(h << 8 | j, -1), 63);    // h = -1 outside the live columns: those keys are negative
             best = mk >= best ? mk : best;
             if (t + 1 < C) {
                 const int Plast = wave_readlane(P, 63);

@@ -12,8 +12,8 @@
 
 // The symbol words and packed counts of the two blocks an extension needs are requested together (four 16-byte
 // lane loads in flight), whether or not the two ranks share a block: one code path for the whole wave, and a repeated
-// block is a cache hit.  Same arithmetic as occ4 (dev_common.h) for ranks k, l >= 0 -- the seeding walk never asks for
-// rank -1: every interval it extends starts at 1 or later (set by L2[c] + 1, kept by the extension formulas).
+// block is a cache hit.  Ranks are >= 0 here -- the seeding walk never asks for rank -1: every interval it extends
+// starts at 1 or later (set by L2[c] + 1, kept by the extension formulas).
 DEV uint32_t mask16(int n)                                  // bit-plane mask of the first n (clamped to 0..16) symbols of a word
 {
     n = n < 0 ? 0 : n > 16 ? 16 : n;
@@ -26,8 +26,15 @@ DEV void cnt_word_m(uint32_t x, uint32_t m, uint32_t& c1, uint32_t& c2, uint32_t
     c2 += __popc(hi & ~lo);
     c1 += __popc(~hi & lo);
 }
-DEV void occ4_two(const DevIndex& ix, uint64_t k, uint64_t l, uint64_t tk[4], uint64_t tl[4])
+// bwt_extend for one symbol, both directions through one code path (cf. extend_one / occ4 in dev_common.h; this form
+// always issues the loads of both blocks at once and never forms the A counts from the block position: the counts of
+// all four symbols up to a rank add up to the rank, so the A column follows from the other three).
+// is_back = 1: the interval of bP for b = c; is_back = 0: upstream's ok[c] of bwt_extend(..., 0), i.e. the interval of
+// P followed by base 3 - c.
+DEV void extend_sm(const DevIndex& ix, uint64_t x0, uint64_t x1, uint64_t size, int c, bool is_back, uint64_t& o0, uint64_t& o1, uint64_t& osz)
 {
+    const uint64_t xa = is_back ? x0 : x1, xb = is_back ? x1 : x0;
+    const uint64_t k = xa - 1, l = xa - 1 + size;
     const uint64_t kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
     const uint64_t bk = kk >> 6, bl = ll >> 6;
     const uint4* pk = ix.occ + 2 * bk;
@@ -39,23 +46,13 @@ DEV void occ4_two(const DevIndex& ix, uint64_t k, uint64_t l, uint64_t tk[4], ui
     cnt_word_m(sk.y, mask16(nk - 16), a1, a2, a3);  cnt_word_m(sl.y, mask16(nl - 16), b1, b2, b3);
     cnt_word_m(sk.z, mask16(nk - 32), a1, a2, a3);  cnt_word_m(sl.z, mask16(nl - 32), b1, b2, b3);
     cnt_word_m(sk.w, mask16(nk - 48), a1, a2, a3);  cnt_word_m(sl.w, mask16(nl - 48), b1, b2, b3);
-    uint64_t c0, c1, c2, c3, d0, d1, d2, d3;
-    occ_unpack(ck, bk, c0, c1, c2, c3);
-    occ_unpack(cl, bl, d0, d1, d2, d3);
-    tk[0] = c0 + (uint32_t)(nk - (int)(a1 + a2 + a3)); tk[1] = c1 + a1; tk[2] = c2 + a2; tk[3] = c3 + a3;
-    tl[0] = d0 + (uint32_t)(nl - (int)(b1 + b2 + b3)); tl[1] = d1 + b1; tl[2] = d2 + b2; tl[3] = d3 + b3;
-}
-
-// bwt_extend for one symbol, both directions through one code path (cf. extend_one in dev_common.h; this form always
-// issues the loads of both blocks at once).  is_back = 1: the interval of bP for b = c; is_back = 0: upstream's ok[c]
-// of bwt_extend(..., 0), i.e. the interval of P followed by base 3 - c.
-DEV void extend_sm(const DevIndex& ix, uint64_t x0, uint64_t x1, uint64_t size, int c, bool is_back, uint64_t& o0, uint64_t& o1, uint64_t& osz)
-{
-    const uint64_t xa = is_back ? x0 : x1, xb = is_back ? x1 : x0;
-    uint64_t tk[4], tl[4];
-    occ4_two(ix, xa - 1, xa - 1 + size, tk, tl);
-    const uint64_t s0 = tl[0] - tk[0], s1 = tl[1] - tk[1], s2 = tl[2] - tk[2], s3 = tl[3] - tk[3];
-    const uint64_t tkc = c == 0 ? tk[0] : c == 1 ? tk[1] : c == 2 ? tk[2] : tk[3];
+    // occ(k, b) and occ(l, b) for b = C, G, T
+    const uint64_t tk1 = ((uint64_t)(ck.w & 0xffu) << 32 | ck.x) + a1, tk2 = ((uint64_t)(ck.w >> 8 & 0xffu) << 32 | ck.y) + a2, tk3 = ((uint64_t)(ck.w >> 16 & 0xffu) << 32 | ck.z) + a3;
+    const uint64_t tl1 = ((uint64_t)(cl.w & 0xffu) << 32 | cl.x) + b1, tl2 = ((uint64_t)(cl.w >> 8 & 0xffu) << 32 | cl.y) + b2, tl3 = ((uint64_t)(cl.w >> 16 & 0xffu) << 32 | cl.z) + b3;
+    const uint64_t s1 = tl1 - tk1, s2 = tl2 - tk2, s3 = tl3 - tk3;
+    const uint64_t s0 = (ll - kk) - s1 - s2 - s3;          // ranks kk+1 and ll+1 are the totals over the four symbols
+    const uint64_t tk0 = kk + 1 - tk1 - tk2 - tk3;
+    const uint64_t tkc = c == 0 ? tk0 : c == 1 ? tk1 : c == 2 ? tk2 : tk3;
     const uint64_t sc = c == 0 ? s0 : c == 1 ? s1 : c == 2 ? s2 : s3;
     const uint64_t l2c = c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3];
     uint64_t other = xb + (xa <= ix.primary && xa + size - 1 >= ix.primary);

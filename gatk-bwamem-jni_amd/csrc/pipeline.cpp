@@ -509,8 +509,8 @@ static std::vector<TileSpec> plan_tiles(const bwamem_batch_s* b, const MemOpt& o
 {
     const char* env_t = getenv("BWAMEM_HIP_TILE");
     const char* env_gb = getenv("BWAMEM_HIP_TILE_GB");
-    const int64_t budget = (int64_t)(env_gb ? atoi(env_gb) : 12) << 30;
-    uint32_t max_T = env_t ? (uint32_t)atoi(env_t) : 196608u;
+    const int64_t budget = (int64_t)(env_gb ? atoi(env_gb) : 24) << 30;
+    uint32_t max_T = env_t ? (uint32_t)atoi(env_t) : 393216u;
     if (even) max_T = std::max(2u, max_T & ~1u);
     std::vector<TileSpec> tiles;
     uint32_t r0 = 0;
