@@ -51,6 +51,8 @@ def load_lib():
     lib.bwamem_hip_batch_align.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
     lib.bwamem_hip_batch_result_bytes.restype = ctypes.c_size_t
     lib.bwamem_hip_batch_result_bytes.argtypes = [ctypes.c_void_p]
+    lib.bwamem_hip_batch_download.restype = ctypes.c_int
+    lib.bwamem_hip_batch_download.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.bwamem_hip_batch_free.argtypes = [ctypes.c_void_p]
     lib.bwamem_hip_stats_get.argtypes = [ctypes.POINTER(Stats)]
     return lib
@@ -132,7 +134,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--genome-bp", type=int, default=3_100_000_000)
     ap.add_argument("--contigs", type=int, default=24)
-    ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads timed through the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-sample", type=int, default=600_000, help="reads timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--keep-image", default=None, help="also copy the index image to this path (profiling helper)")
     ap.add_argument("--dump-request", default=None, help="write the first --cpu-sample reads as a request file (profiling helper)")
     ap.add_argument("--image", default=None, help="use an existing .img (e.g. GATK's Homo_sapiens_assembly38.fasta.img) instead of the synthetic genome")
@@ -223,6 +225,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st_timed = Stats(); lib.bwamem_hip_stats_get(ctypes.byref(st_timed))
+    # keep the records of the LAST reads of the timed batch (four tiles and a seeding chunk in flight) for the parity check below
+    tail_bytes, S2 = None, 0
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        import bwalib as B
+        if not os.path.exists(B.ORACLE_LIB):
+            B.build_oracle()
+        orc_dll = ctypes.CDLL(B.ORACLE_LIB)
+        S2 = min(args.cpu_sample, 50000, R)
+        total = lib.bwamem_hip_batch_result_bytes(batch)
+        buf = (ctypes.c_ubyte * total)()
+        if lib.bwamem_hip_batch_download(batch, buf) == 0 and hasattr(orc_dll, "oracle_response_offsets"):
+            offs = (ctypes.c_int64 * (R + 1))()                 # record boundaries of the whole response (C walk in the checker library)
+            ro = orc_dll.oracle_response_offsets
+            ro.restype = ctypes.c_int
+            ro.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p]
+            if ro(buf, total, R, offs) != 0 or offs[R] != total:
+                raise SystemExit("response of the timed batch does not parse")
+            tail_bytes = bytes(memoryview(buf)[offs[R - S2]:offs[R]])
+        del buf
     # Roofline pass (untimed): during the timed steps several tiles are in flight on separate streams, so the
     # HIP-event interval of one launch also contains other tiles' kernels.  One extra step with a single tile in
     # flight gives per-launch durations that mean what rocprofv3 --kernel-trace reports for the same kernel.
@@ -301,9 +322,29 @@ def main():
         if got is not None:
             a, b = B.split_response(got, S), B.split_response(want, S)
             ident = sum(1 for x, y in zip(a, b) if x == y) / S
+        # second sample: the LAST reads of the batch, taken from the big batch's own response (so the seeding chunks, tiles
+        # and interval-store reuse of a 10 M-read call are what is being checked), against the oracle run on that slice
+        # with its position in the call (the tie-breaking hash of mem_mark_primary_se uses the read index)
+        tail = None
+        if tail_bytes is not None and hasattr(orc.dll, "oracle_createAlignmentsAt"):
+            req2 = struct.pack("<i", S2) + payload[R - S2:].cpu().numpy().tobytes()
+            fn = orc.dll.oracle_createAlignmentsAt
+            fn.restype = ctypes.c_void_p
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_int64]
+            ho2 = orc.open_index(img)
+            rb2 = ctypes.create_string_buffer(req2, len(req2)); sz2 = ctypes.c_size_t()
+            ob2 = ctypes.create_string_buffer(bytes(oo), 168)
+            p2 = fn(ho2, ob2, None, rb2, ctypes.byref(sz2), rank * R + R - S2)
+            want2 = ctypes.string_at(p2, sz2.value) if p2 else None
+            orc.destroy_index(ho2)
+            if want2 is not None:
+                a2, b2 = B.split_response(tail_bytes, S2), B.split_response(want2, S2)
+                tail = {"reads": S2, "from": "the last reads of the timed batch's own response", "frac_identical_records": sum(1 for x, y in zip(a2, b2) if x == y) / S2}
         out["cpu_baseline"] = {"value": S / tcpu, "unit": "reads/s", "cores": cores, "kind": "port",
                                "sample": "first %d reads of the same batch through oracle/ (own CPU restatement, not libbwa), %d threads, %.1f s" % (S, cores, tcpu)}
         out["parity_sample"] = {"reads": S, "frac_identical_records": ident}
+        if tail is not None:
+            out["parity_sample_tail"] = tail
 
     if rank == 0:
         print(json.dumps(out), flush=True)

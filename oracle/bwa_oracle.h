@@ -148,6 +148,8 @@ o_idx_t *oracle_openIndex(int fd);
 int   oracle_destroyIndex(o_idx_t *idx);
 void *oracle_getRefContigNames(o_idx_t *idx, size_t *sz);
 void *oracle_createAlignments(o_idx_t *idx, o_opt_t *opt, o_pestat_t *pes, char *seqs, size_t *sz);
+int oracle_response_offsets(const uint8_t *buf, size_t len, uint32_t n_reads, int64_t *offs);   /* record boundaries of a response */
+void *oracle_createAlignmentsAt(o_idx_t *idx, o_opt_t *opt, o_pestat_t *pes, char *seqs, size_t *sz, int64_t read_id0);   /* a slice of a larger call */
 void *oracle_createDefaultOptions(void);
 void  oracle_free(void *p);
 

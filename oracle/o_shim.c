@@ -195,7 +195,16 @@ static void run_phase(work_t *proto, int phase)
 	free(th); free(w);
 }
 
+void *oracle_createAlignmentsAt(o_idx_t *idx, o_opt_t *opt, o_pestat_t *pes0, char *pSeq, size_t *pBufSize, int64_t read_id0);
+
 void *oracle_createAlignments(o_idx_t *idx, o_opt_t *opt, o_pestat_t *pes0, char *pSeq, size_t *pBufSize)
+{
+	return oracle_createAlignmentsAt(idx, opt, pes0, pSeq, pBufSize, 0);
+}
+
+/* read_id0: index of the first read within the (larger) call these reads are a slice of -- upstream's n_processed, which
+ * enters the tie-breaking hash of mem_mark_primary_se (bwamem.c) */
+void *oracle_createAlignmentsAt(o_idx_t *idx, o_opt_t *opt, o_pestat_t *pes0, char *pSeq, size_t *pBufSize, int64_t read_id0)
 {
 	uint32_t nSeqs = *(uint32_t*)pSeq, i;
 	o_read_t *seqs = calloc(nSeqs ? nSeqs : 1, sizeof(o_read_t));
@@ -210,7 +219,7 @@ void *oracle_createAlignments(o_idx_t *idx, o_opt_t *opt, o_pestat_t *pes0, char
 		pSeq += l + 1;
 	}
 	memset(&w, 0, sizeof w);
-	w.opt = opt; w.idx = idx; w.seqs = seqs; w.n_processed = 0; w.pes = pes;
+	w.opt = opt; w.idx = idx; w.seqs = seqs; w.n_processed = read_id0; w.pes = pes;
 	w.regs = calloc(nSeqs ? nSeqs : 1, sizeof(o_alnreg_v));
 	w.n_units = (opt->flag & O_F_PE) ? nSeqs >> 1 : nSeqs;
 	w.n_threads = opt->n_threads > 0 ? opt->n_threads : 1;
@@ -229,6 +238,37 @@ void *oracle_createAlignments(o_idx_t *idx, o_opt_t *opt, o_pestat_t *pes0, char
 	free(seqs);
 	*pBufSize = tot;
 	return res;
+}
+
+/* byte offset of every read's records in a response (the reference's bufLen walk, jnibwa.c:99-124); offs[n_reads] = end.
+ * Returns 0, or -1 when the walk runs past len. */
+int oracle_response_offsets(const uint8_t *buf, size_t len, uint32_t n_reads, int64_t *offs)
+{
+	size_t off = 0;
+	uint32_t r;
+	for (r = 0; r < n_reads; ++r) {
+		int32_t na, a;
+		offs[r] = (int64_t)off;
+		if (off + 4 > len) return -1;
+		memcpy(&na, buf + off, 4); off += 4;
+		for (a = 0; a < na; ++a) {
+			int32_t fm, flag, nc, nmd, nxa;
+			if (off + 4 > len) return -1;
+			memcpy(&fm, buf + off, 4); off += 4;
+			flag = (fm >> 16) & 0xffff;
+			if (!(flag & 4)) {
+				if (off + 24 > len) return -1;
+				memcpy(&nc, buf + off + 20, 4); off += 24 + 4 * (size_t)nc;
+				if (off + 4 > len) return -1;
+				memcpy(&nmd, buf + off, 4); off += 4 + (((size_t)nmd + 3) & ~(size_t)3);
+				if (off + 4 > len) return -1;
+				memcpy(&nxa, buf + off, 4); off += 4 + (((size_t)nxa + 3) & ~(size_t)3);
+			}
+			if ((flag & 9) == 1) off += 12;
+		}
+	}
+	offs[n_reads] = (int64_t)off;
+	return off <= len ? 0 : -1;
 }
 
 /* ---- test hooks: expose the order-exact sort on (x, y) pairs compared by x only, so the tie permutation is observable ---- */

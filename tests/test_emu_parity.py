@@ -64,6 +64,8 @@ def test_emu_concurrent_tiles(emu, oracle, small_genome, monkeypatch):
     monkeypatch.setenv("BWAMEM_HIP_TILE", "7")
     monkeypatch.setenv("BWAMEM_HIP_STREAMS", "3")
     _cmp(emu, oracle, img, reads)
+    monkeypatch.setenv("BWAMEM_HIP_SEED_CHUNK", "10")               # seeding chunks of one tile: both interval stores get reused
+    _cmp(emu, oracle, img, reads)
 
 
 def test_emu_long_reads_seed_rescoring(emu, oracle, small_genome):

@@ -139,6 +139,21 @@ def test_multi_tile_equals_single_tile(hip_lib, oracle, small_genome, monkeypatc
     assert whole == tiled
 
 
+def test_many_seeding_chunks_and_tiles(hip_lib, oracle, medium_genome, monkeypatch):
+    """seeding runs in chunks of several tiles, one chunk ahead of the tile workers, into two interval stores that are
+    reused every other chunk: many small chunks and tiles must give the single-launch bytes (and the oracle's)"""
+    seqs, img = medium_genome
+    reads = B.simulate_reads(seqs, 30000, length=150, seed=77, sub=0.02, indel=0.003, n_rate=0.002, random_frac=0.02)
+    whole = _parity(hip_lib, oracle, img, reads)
+    monkeypatch.setenv("BWAMEM_HIP_TILE", "1300")
+    monkeypatch.setenv("BWAMEM_HIP_SEED_CHUNK", "3000")
+    monkeypatch.setenv("BWAMEM_HIP_STREAMS", "4")
+    assert _parity(hip_lib, oracle, img, reads) == whole
+    monkeypatch.setenv("BWAMEM_HIP_SEED_AHEAD", "0")
+    monkeypatch.setenv("BWAMEM_HIP_STREAMS", "2")
+    assert _parity(hip_lib, oracle, img, reads) == whole
+
+
 def test_parity_medium_genome(hip_lib, oracle, medium_genome):
     seqs, img = medium_genome
     reads = B.simulate_reads(seqs, 20000, length=150, seed=42)
