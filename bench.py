@@ -85,7 +85,24 @@ def synth_genome(torch, dev, total_bp, n_contigs, seed):
     return codes, contigs
 
 
-def synth_reads(torch, dev, codes, contigs, n, length, seed):
+def synth_pairs(torch, dev, codes, contigs, n_pairs, length, seed):
+    """config 2 of BASELINE.json: FR pairs, insert size ~ N(300, 30) clipped to [length, 600]; mates interleaved as Java sends them."""
+    g = torch.Generator(device=dev); g.manual_seed(seed ^ 0x9E37)
+    total = codes.numel()
+    span = 640 + length
+    bounds = torch.tensor([0] + [l for _, l in contigs], device=dev).cumsum(0)
+    pos1 = (torch.rand(n_pairs, generator=g, device=dev, dtype=torch.float64) * (total - span)).long()
+    ci = torch.searchsorted(bounds, pos1, right=True) - 1
+    pos1 = torch.where(pos1 + span <= bounds[ci + 1], pos1, torch.clamp(bounds[ci + 1] - span, min=0))
+    isize = torch.clamp((torch.randn(n_pairs, generator=g, device=dev) * 30 + 300).long(), min=length, max=600)
+    pos2 = pos1 + isize - length
+    fs = torch.rand(n_pairs, generator=g, device=dev) < 0.5
+    r1 = synth_reads(torch, dev, codes, contigs, n_pairs, length, seed, pos=torch.where(fs, pos1, pos2), rc=~fs)
+    r2 = synth_reads(torch, dev, codes, contigs, n_pairs, length, seed + 1, pos=torch.where(fs, pos2, pos1), rc=fs)
+    return torch.stack([r1, r2], dim=1).reshape(2 * n_pairs, length + 1).contiguous()
+
+
+def synth_reads(torch, dev, codes, contigs, n, length, seed, pos=None, rc=None):
     """uniform position/strand, 1 % substitutions, 0.02 %/base indels (one event per affected
     read, geometric length), 0.1 % N, 0.5 % random reads.  Returns the request payload (n x (length+1) ASCII, NUL-terminated)."""
     g = torch.Generator(device=dev); g.manual_seed(seed)
@@ -93,10 +110,11 @@ def synth_reads(torch, dev, codes, contigs, n, length, seed):
     slack = 40
     # start positions that keep length+slack bases inside one contig
     bounds = torch.tensor([0] + [l for _, l in contigs], device=dev).cumsum(0)
-    pos = (torch.rand(n, generator=g, device=dev, dtype=torch.float64) * (total - length - slack)).long()
-    ci = torch.searchsorted(bounds, pos, right=True) - 1
-    end_ok = pos + length + slack <= bounds[ci + 1]
-    pos = torch.where(end_ok, pos, torch.clamp(bounds[ci + 1] - length - slack, min=0))
+    if pos is None:
+        pos = (torch.rand(n, generator=g, device=dev, dtype=torch.float64) * (total - length - slack)).long()
+        ci = torch.searchsorted(bounds, pos, right=True) - 1
+        end_ok = pos + length + slack <= bounds[ci + 1]
+        pos = torch.where(end_ok, pos, torch.clamp(bounds[ci + 1] - length - slack, min=0))
     col = torch.arange(length, device=dev)
     # one indel event for a fraction of reads
     has = torch.rand(n, generator=g, device=dev) < (0.0002 * length)
@@ -113,7 +131,8 @@ def synth_reads(torch, dev, codes, contigs, n, length, seed):
     b = torch.where(ins_zone, rnd, b)
     sub = torch.rand(n, length, generator=g, device=dev) < 0.01
     b = torch.where(sub, (b + 1 + rnd % 3) % 4, b)
-    rc = torch.rand(n, generator=g, device=dev) < 0.5
+    if rc is None:
+        rc = torch.rand(n, generator=g, device=dev) < 0.5
     b = torch.where(rc[:, None], torch.flip(3 - b, [1]), b)
     junk = torch.rand(n, generator=g, device=dev) < 0.005
     b = torch.where(junk[:, None], rnd, b)
@@ -135,6 +154,8 @@ def main():
     ap.add_argument("--genome-bp", type=int, default=3_100_000_000)
     ap.add_argument("--contigs", type=int, default=24)
     ap.add_argument("--cpu-sample", type=int, default=600_000, help="reads timed through the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--paired", action="store_true", help="auxiliary measurement (BASELINE.json config 2): --reads is then the number of reads = 2 x pairs; "
+                    "the library infers the insert-size statistics per call; metric/roofline fields are still reported for the seeding kernel")
     ap.add_argument("--keep-image", default=None, help="also copy the index image to this path (profiling helper)")
     ap.add_argument("--dump-request", default=None, help="write the first --cpu-sample reads as a request file (profiling helper)")
     ap.add_argument("--image", default=None, help="use an existing .img (e.g. GATK's Homo_sapiens_assembly38.fasta.img) instead of the synthetic genome")
@@ -181,7 +202,7 @@ def main():
 
     # ---- request resident in HBM (not timed)
     L, R = args.read_len, args.reads
-    payload = synth_reads(torch, dev, codes, contigs, R, L, 42 + rank)
+    payload = synth_pairs(torch, dev, codes, contigs, R // 2, L, 42 + rank) if args.paired else synth_reads(torch, dev, codes, contigs, R, L, 42 + rank)
     note("%d reads generated on the device" % R)
     del codes
     torch.cuda.empty_cache()
@@ -200,6 +221,8 @@ def main():
     p = lib.jnibwa_createDefaultOptions()
     opts = ctypes.create_string_buffer(ctypes.string_at(p, 168), 168)
     lib.jnibwa_free(p)
+    if args.paired:
+        struct.pack_into("<i", opts, 60, struct.unpack_from("<i", opts, 60)[0] | 0x2 | int(os.environ.get("BENCH_EXTRA_FLAG", "0"), 0))   # mem_opt_t.flag |= MEM_F_PE
 
     def step():
         if lib.bwamem_hip_batch_align(idx, opts, None, batch, rank * R) != 0:
@@ -227,7 +250,7 @@ def main():
     st_timed = Stats(); lib.bwamem_hip_stats_get(ctypes.byref(st_timed))
     # keep the records of the LAST reads of the timed batch (four tiles and a seeding chunk in flight) for the parity check below
     tail_bytes, S2 = None, 0
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and not args.paired:     # (paired: the batch-wide insert-size statistics differ from a slice's)
         import bwalib as B
         if not os.path.exists(B.ORACLE_LIB):
             B.build_oracle()
@@ -288,7 +311,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32/int64", "data": "synthetic",
             "config": {"workload": "%d x %dbp single-end synthetic reads per GPU vs synthetic GRCh38-scale genome (%d bp, %d contigs, 5%% diverged repeats), full index in HBM" % (R, L, args.genome_bp, args.contigs),
                        "reads_per_gpu": R, "read_len": L, "genome_bp": args.genome_bp, "index_build_s": round(t_index, 1), "response_bytes": result_bytes,
-                       "parallelism": "read-sharded x%d, no collectives" % world},
+                       "parallelism": "read-sharded x%d, no collectives" % world, "paired_end": bool(args.paired)},
             "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_note, "measured_in": "extra untimed step with nothing else on the GPU: one tile in flight, seeding chunks not overlapped (see DESIGN.md section 5)", "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": int(st.n_launch_seed),
                          "n_ext_per_read": st.n_ext / max(1, st.n_reads)},
@@ -309,6 +332,8 @@ def main():
         cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
         ho = orc.open_index(img)
         oo = B.set_opt(orc.default_options(), n_threads=cores)
+        if args.paired:
+            B.set_opt(oo, flag=B.get_opt(oo, "flag") | B.MEM_F_PE)
         tc = time.time()
         want = orc.align_raw(ho, oo, req)
         tcpu = time.time() - tc

@@ -11,6 +11,7 @@
 #include "kernels.h"
 #include "post_common.h"
 #include "sw_common.h"
+#include "wave_ops.h"
 
 
 // ------------------------------------------------------------------ insert-size candidates
@@ -54,37 +55,75 @@ __global__ void k_pestat_cand(DevIndex ix, MemOpt opt, TileView tv, int8_t* cand
 }
 
 // ------------------------------------------------------------------ mate rescue (mem_matesw)
-DEV int matesw(const DevIndex& ix, const MemOpt& opt, PostScratch& S, SwScratch& W, const MemPestat* pes, const AlnReg& a,
+// One ksw_align2 per requesting lane, run by the whole wavefront (sw_align2_wave); every lane of the wave calls this the
+// same number of times, `want` says whether the lane has a request.  Queries too long for the LDS stripes fall back to the
+// lane's own scalar kernel.
+DEV KswR serve_sw(const DevIndex& ix, const MemOpt& opt, bool want, const SwIn& I, int qlen, int tlen, int xtra, const SwLds& L, SwScratch& W, int lane, int& err)
+{
+    KswR mine; mine.score = 0; mine.te = mine.qe = mine.score2 = mine.te2 = mine.tb = mine.qb = -1;
+    const int p = (xtra & KSW_XBYTE) ? 16 : 8;
+    const bool fits = ((qlen + p - 1) / p) * p <= L.cap_cells;
+    if (want && !fits) mine = sw_align2(ix, opt, I, qlen, tlen, xtra, W, err);
+    unsigned long long pend = __ballot(want && fits);
+    while (pend) {
+        const int src = __ffsll((long long)pend) - 1;
+        pend &= pend - 1ull;
+        SwIn U;
+        {
+            const uint64_t pm = (uint64_t)(uintptr_t)I.ms;
+            U.ms = (const uint8_t*)(uintptr_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)(pm >> 32), src) << 32 | (uint32_t)__shfl((int)(uint32_t)pm, src));
+            U.l_ms = __shfl(I.l_ms, src); U.is_rev = __shfl(I.is_rev, src); U.qrev = 0; U.trev = 0;
+            U.t0 = (int64_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)((uint64_t)I.t0 >> 32), src) << 32 | (uint32_t)__shfl((int)(uint32_t)(uint64_t)I.t0, src));
+        }
+        const int uq = __shfl(qlen, src), ut = __shfl(tlen, src), ux = __shfl(xtra, src);
+        int e2 = 0;
+        const KswR res = sw_align2_wave(ix, opt, U, uq, ut, ux, L, lane, e2);
+        if (lane == src) { mine = res; err |= e2; }
+    }
+    return mine;
+}
+
+// mem_matesw for one anchor per lane; wave-uniform control (every lane passes through the same four orientations), `on`
+// says whether the lane has an anchor at all
+DEV int matesw(const DevIndex& ix, const MemOpt& opt, PostScratch& S, SwScratch& W, const SwLds& L, int lane, bool on, const MemPestat* pes, const AlnReg& a,
                int l_ms, const uint8_t* ms, int& n_ma, AlnReg* ma, int cap_ma, int& err)
 {
     const int64_t l_pac = ix.l_pac;
     int i, r, skip[4], n = 0, rid = -1;
     for (r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
-    for (i = 0; i < n_ma; ++i) {
+    if (on) for (i = 0; i < n_ma; ++i) {
         int64_t dist;
         r = infer_dir(l_pac, a.rb, ma[i].rb, &dist);
         if (dist >= pes[r].low && dist <= pes[r].high) skip[r] = 1;
     }
-    if (skip[0] + skip[1] + skip[2] + skip[3] == 4) return 0;
+    if (skip[0] + skip[1] + skip[2] + skip[3] == 4) on = false;
     for (r = 0; r < 4; ++r) {
-        if (skip[r]) continue;
+        const bool live = on && !skip[r];
         int is_rev = (r >> 1 != (r & 1));
         int is_larger = !(r >> 1);
-        int64_t rb, re;
-        if (!is_rev) {
-            rb = is_larger ? a.rb + pes[r].low : a.rb - pes[r].high;
-            re = (is_larger ? a.rb + pes[r].high : a.rb - pes[r].low) + l_ms;
-        } else {
-            rb = (is_larger ? a.rb + pes[r].low : a.rb - pes[r].high) - l_ms;
-            re = is_larger ? a.rb + pes[r].high : a.rb - pes[r].low;
+        int64_t rb = 0, re = 0;
+        bool want = false;
+        SwIn I; I.ms = ms; I.l_ms = l_ms; I.is_rev = is_rev; I.qrev = 0; I.t0 = 0; I.trev = 0;
+        int xtra = 0;
+        if (live) {
+            if (!is_rev) {
+                rb = is_larger ? a.rb + pes[r].low : a.rb - pes[r].high;
+                re = (is_larger ? a.rb + pes[r].high : a.rb - pes[r].low) + l_ms;
+            } else {
+                rb = (is_larger ? a.rb + pes[r].low : a.rb - pes[r].high) - l_ms;
+                re = is_larger ? a.rb + pes[r].high : a.rb - pes[r].low;
+            }
+            if (rb < 0) rb = 0;
+            if (re > l_pac << 1) re = l_pac << 1;
+            if (rb < re) bns_clamp(ix, rb, (rb + re) >> 1, re, rid);
+            if (a.rid == rid && re - rb >= opt.min_seed_len) {
+                want = true;
+                xtra = KSW_XSUBO | KSW_XSTART | (l_ms * opt.a < 250 ? KSW_XBYTE : 0) | (opt.min_seed_len * opt.a);
+                I.t0 = rb;
+            }
         }
-        if (rb < 0) rb = 0;
-        if (re > l_pac << 1) re = l_pac << 1;
-        if (rb < re) bns_clamp(ix, rb, (rb + re) >> 1, re, rid);
-        if (a.rid == rid && re - rb >= opt.min_seed_len) {
-            int xtra = KSW_XSUBO | KSW_XSTART | (l_ms * opt.a < 250 ? KSW_XBYTE : 0) | (opt.min_seed_len * opt.a);
-            SwIn I; I.ms = ms; I.l_ms = l_ms; I.is_rev = is_rev; I.qrev = 0; I.t0 = rb; I.trev = 0;
-            KswR aln = sw_align2(ix, opt, I, l_ms, (int)(re - rb), xtra, W, err);
+        const KswR aln = serve_sw(ix, opt, want, I, l_ms, (int)(re - rb), xtra, L, W, lane, err);
+        if (want) {
             if (aln.score >= opt.min_seed_len && aln.qb >= 0) {
                 AlnReg b;
                 b.rb = b.re = 0; b.qb = b.qe = 0; b.rid = 0; b.score = b.truesc = b.sub = b.alt_sc = b.csub = b.sub_n = b.w = b.seedcov = 0;
@@ -99,16 +138,18 @@ DEV int matesw(const DevIndex& ix, const MemOpt& opt, PostScratch& S, SwScratch&
                 b.csub = aln.score2;
                 b.secondary = -1;
                 b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
-                if (n_ma >= cap_ma) { err |= ERR_SCRATCH; return n; }
-                ++n_ma;
-                for (i = 0; i < n_ma - 1; ++i) if (ma[i].score < b.score) break;
-                int tmp = i;
-                for (i = n_ma - 1; i > tmp; --i) ma[i] = ma[i - 1];
-                ma[i] = b;
+                if (n_ma >= cap_ma) { err |= ERR_SCRATCH; on = false; }
+                else {
+                    ++n_ma;
+                    for (i = 0; i < n_ma - 1; ++i) if (ma[i].score < b.score) break;
+                    int tmp = i;
+                    for (i = n_ma - 1; i > tmp; --i) ma[i] = ma[i - 1];
+                    ma[i] = b;
+                }
             }
             ++n;
         }
-        if (n) n_ma = sort_dedup_patch(ix, opt, S, 0, n_ma, ma);
+        if (on && !skip[r] && n) n_ma = sort_dedup_patch(ix, opt, S, 0, n_ma, ma);
     }
     return n;
 }
@@ -190,26 +231,52 @@ struct PeView {
     int64_t scratch_per_pair;
     void* vpool;              // Pair64 per region slot (indexed by reg_off of the pair's first read)
     int cap_h, cap_b, cap_u;
+    int lds_cells;            // k_pe_pair: cells per LDS stripe of the wave-cooperative rescue SW
 };
 
-__global__ void k_final_pe(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3)
+// what the pairing stage decides for one pair and the record stage needs back
+struct PeState { int32_t paired, z0, z1, n_pri0, n_pri1, extra_flag, q_se0, q_se1; };
+
+// common per-pair set-up of the two stages
+struct PeCtx {
+    int rd[2]; const uint8_t* seq[2]; int l_seq[2]; AlnReg* a[2]; int n[2], cap[2]; int32_t* zb[2];
+};
+DEV PeCtx pe_ctx(const TileView& tv, const PeView& pv, int pi)
 {
-    int pi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pi >= tv.n_reads >> 1) return;
+    PeCtx c;
+    c.rd[0] = pi << 1; c.rd[1] = pi << 1 | 1;
+    for (int i = 0; i < 2; ++i) {
+        c.seq[i] = tv.seq + tv.seq_off[c.rd[i]];
+        c.l_seq[i] = (int)(tv.seq_off[c.rd[i] + 1] - tv.seq_off[c.rd[i]] - 1);
+        c.a[i] = pv.regs + pv.reg_off[c.rd[i]];
+        c.cap[i] = (int)(pv.reg_off[c.rd[i] + 1] - pv.reg_off[c.rd[i]]);
+        c.n[i] = pv.n_regs[c.rd[i]];
+        c.zb[i] = pv.ints + 2 * pv.reg_off[c.rd[i]];
+    }
+    return c;
+}
+
+// mem_sam_pe, first half (one lane per pair): mate rescue, primary marking, pairing and the mapping-quality decisions.
+// Regions whose CIGAR needs a banded global alignment are then listed as jobs for k_gcigar_lane / k_gcigar (any region of
+// either mate can end up in a record or an XA tag, so all of them are listed), and the record stage picks the results up:
+// a one-lane DP inside this kernel would stall the other 63 pairs of the wave.
+__global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3, PeState* states)
+{
+    HIP_DYNAMIC_SHARED(int32_t, sw_lds)
+    const int lane = threadIdx.x & 63;
+    const int n_pairs = tv.n_reads >> 1;
+    const bool valid = (int)(blockIdx.x * blockDim.x + threadIdx.x) < n_pairs;     // lanes past the end stay for the wave-cooperative rescue
+    int pi = valid ? (int)(blockIdx.x * blockDim.x + threadIdx.x) : (n_pairs > 0 ? n_pairs - 1 : 0);
+    if (n_pairs <= 0) return;
     const MemPestat pes[4] = { p0, p1, p2, p3 };
-    const int rd[2] = { pi << 1, pi << 1 | 1 };
+    PeCtx c = pe_ctx(tv, pv, pi);
+    const int* rd = c.rd; const uint8_t** seq = c.seq; int* l_seq = c.l_seq; AlnReg** a = c.a; int* n = c.n; int* cap = c.cap; int32_t** zb = c.zb;
     PostScratch S = post_scratch_for(tv, rd[0]);
     int err = 0;
-    const uint8_t* seq[2]; int l_seq[2]; AlnReg* a[2]; int n[2], cap[2]; int32_t* zb[2]; OutBuf ob[2];
-    for (int i = 0; i < 2; ++i) {
-        seq[i] = tv.seq + tv.seq_off[rd[i]];
-        l_seq[i] = (int)(tv.seq_off[rd[i] + 1] - tv.seq_off[rd[i]] - 1);
-        a[i] = pv.regs + pv.reg_off[rd[i]];
-        cap[i] = (int)(pv.reg_off[rd[i] + 1] - pv.reg_off[rd[i]]);
-        n[i] = pv.n_regs[rd[i]];
-        zb[i] = pv.ints + 2 * pv.reg_off[rd[i]];
-        ob[i].p = tv.out + (size_t)rd[i] * tv.out_cap; ob[i].cap = tv.out_cap; ob[i].len = 0; ob[i].ovf = false;
-    }
+    SwLds L;                                                // stripes of the wave-cooperative mate rescue
+    L.cap_cells = pv.lds_cells; L.cap_b = pv.cap_b;
+    L.H0 = sw_lds; L.H1 = L.H0 + L.cap_cells; L.E = L.H1 + L.cap_cells; L.Hmax = L.E + L.cap_cells; L.Q = L.Hmax + L.cap_cells;
+    L.b = (uint64_t*)(L.Q + L.cap_cells);
     // scratch carve-up
     uint8_t* sp = pv.scratch + (size_t)pi * pv.scratch_per_pair;
     SwScratch W;
@@ -225,17 +292,24 @@ __global__ void k_final_pe(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemP
     const int cap_u = pv.cap_u;
 
     const uint64_t id = (uint64_t)((tv.read_id0 >> 1) + pi);
-    int z[2] = { 0, 0 }, o = 0, subo = 0, n_sub = 0, extra_flag = 1, n_pri[2];
+    int z[2] = { 0, 0 }, o = 0, subo = 0, n_sub = 0, extra_flag = 1, n_pri[2], q_se[2] = { 0, 0 };
     if (!(opt.flag & MEM_F_NO_RESCUE)) {                       // mate rescue from the best hits of each end
         for (int i = 0; i < 2; ++i) {
             n_anch[i] = 0;
-            for (int j = 0; j < n[i]; ++j)
+            if (valid) for (int j = 0; j < n[i]; ++j)
                 if (a[i][j].score >= a[i][0].score - opt.pen_unpaired) { if (n_anch[i] < opt.max_matesw) anchors[i][n_anch[i]] = a[i][j]; ++n_anch[i]; }
         }
-        for (int i = 0; i < 2; ++i)
-            for (int j = 0; j < n_anch[i] && j < opt.max_matesw; ++j)
-                matesw(ix, opt, S, W, pes, anchors[i][j], l_seq[!i], seq[!i], n[!i], a[!i], cap[!i], err);
+        for (int i = 0; i < 2; ++i) {                          // the wave walks the anchors together: the rescue SW is wave-cooperative
+            const int mine = n_anch[i] < opt.max_matesw ? n_anch[i] : opt.max_matesw;
+            const int most = wave_max(mine);
+            for (int j = 0; j < most; ++j) {
+                AlnReg anc;
+                if (j < mine) anc = anchors[i][j]; else { anc = a[0][0]; }
+                matesw(ix, opt, S, W, L, lane, j < mine, pes, anc, l_seq[!i], seq[!i], n[!i], a[!i], cap[!i], err);
+            }
+        }
     }
+    if (!valid) return;
     n_pri[0] = mark_primary_se(opt, n[0], a[0], (int64_t)(id << 1 | 0), zb[0]);
     n_pri[1] = mark_primary_se(opt, n[1], a[1], (int64_t)(id << 1 | 1), zb[1]);
     if (opt.flag & MEM_F_PRIMARY5) { reorder_primary5(opt.T, n[0], a[0]); reorder_primary5(opt.T, n[1], a[1]); }
@@ -243,7 +317,7 @@ __global__ void k_final_pe(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemP
     bool paired = false;
     if (!(opt.flag & MEM_F_NOPAIRING) && n_pri[0] && n_pri[1]
         && (o = mem_pair(ix, opt, pes, a[0], a[1], (int)id, &subo, &n_sub, z, n_pri, v, u, cap_u, err)) > 0) {
-        int is_multi[2], q_pe, score_un, q_se[2];
+        int is_multi[2], q_pe, score_un;
         for (int i = 0; i < 2; ++i) {
             int j;
             for (j = 1; j < n_pri[i]; ++j)
@@ -263,16 +337,16 @@ __global__ void k_final_pe(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemP
             if (q_pe > 60) q_pe = 60;
             q_pe = (int)(q_pe * (1. - .5 * (a[0][0].frac_rep + a[1][0].frac_rep)) + .499);
             if (o > score_un) {                                 // the paired alignment is preferred
-                AlnReg* c[2] = { &a[0][z[0]], &a[1][z[1]] };
+                AlnReg* cc[2] = { &a[0][z[0]], &a[1][z[1]] };
                 for (int i = 0; i < 2; ++i) {
-                    if (c[i]->secondary >= 0) { c[i]->sub = a[i][c[i]->secondary].score; c[i]->secondary = -2; }
-                    q_se[i] = approx_mapq_se(ix, opt, S, *c[i]);
+                    if (cc[i]->secondary >= 0) { cc[i]->sub = a[i][cc[i]->secondary].score; cc[i]->secondary = -2; }
+                    q_se[i] = approx_mapq_se(ix, opt, S, *cc[i]);
                 }
                 q_se[0] = q_se[0] > q_pe ? q_se[0] : q_pe < q_se[0] + 40 ? q_pe : q_se[0] + 40;
                 q_se[1] = q_se[1] > q_pe ? q_se[1] : q_pe < q_se[1] + 40 ? q_pe : q_se[1] + 40;
                 extra_flag |= 2;
-                q_se[0] = q_se[0] < RAW_MAPQ(c[0]->score - c[0]->csub, opt.a) ? q_se[0] : RAW_MAPQ(c[0]->score - c[0]->csub, opt.a);
-                q_se[1] = q_se[1] < RAW_MAPQ(c[1]->score - c[1]->csub, opt.a) ? q_se[1] : RAW_MAPQ(c[1]->score - c[1]->csub, opt.a);
+                q_se[0] = q_se[0] < RAW_MAPQ(cc[0]->score - cc[0]->csub, opt.a) ? q_se[0] : RAW_MAPQ(cc[0]->score - cc[0]->csub, opt.a);
+                q_se[1] = q_se[1] < RAW_MAPQ(cc[1]->score - cc[1]->csub, opt.a) ? q_se[1] : RAW_MAPQ(cc[1]->score - cc[1]->csub, opt.a);
             } else {
                 z[0] = z[1] = 0;
                 q_se[0] = approx_mapq_se(ix, opt, S, a[0][0]);
@@ -286,36 +360,70 @@ __global__ void k_final_pe(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemP
                     a[i][z[i]].secondary_all = -1;
                 }
             }
-            // records: h[i] (+ an ALT supplementary g[i]); each needs the mate's position
-            MateInfo hm[2];
-            int n_aa[2] = { 1, 1 }, alt_k[2] = { -1, -1 };
-            for (int i = 0; i < 2; ++i) {
-                AlnRec h = reg2aln(ix, opt, S, l_seq[i], seq[i], &a[i][z[i]]);
-                hm[i] = mate_of(h);
-                if (n_pri[i] < n[i]) {
-                    const AlnReg* p = &a[i][n_pri[i]];
-                    if (!(p->score < opt.T || p->secondary >= 0 || !p->is_alt)) { alt_k[i] = n_pri[i]; n_aa[i] = 2; }
-                }
-            }
-            for (int i = 0; i < 2; ++i) {
-                int32_t *cnt = 0, *has_alt = 0;
-                if (!(opt.flag & MEM_F_ALL) && n[i] > 0) {
-                    cnt = zb[i]; has_alt = zb[i] + n[i];
-                    if (xa_prepare(opt, n[i], a[i], cnt, has_alt) == 0) cnt = has_alt = 0;
-                }
-                AlnRec h = reg2aln(ix, opt, S, l_seq[i], seq[i], &a[i][z[i]]);
-                h.mapq = q_se[i];
-                h.flag |= 0x40 << i | extra_flag;
-                aln2out(ix, opt, S, ob[i], n_aa[i], 0, h, &hm[!i], l_seq[i], seq[i], n[i], a[i], cnt, has_alt, cnt ? z[i] : -1);
-                if (alt_k[i] >= 0) {
-                    AlnRec g = reg2aln(ix, opt, S, l_seq[i], seq[i], &a[i][alt_k[i]]);
-                    g.flag |= 0x800 | 0x40 << i | extra_flag;
-                    aln2out(ix, opt, S, ob[i], n_aa[i], 1, g, &hm[!i], l_seq[i], seq[i], n[i], a[i], cnt, has_alt, cnt ? alt_k[i] : -1);
-                }
+        }
+    }
+    PeState st; st.paired = paired; st.z0 = z[0]; st.z1 = z[1]; st.n_pri0 = n_pri[0]; st.n_pri1 = n_pri[1]; st.extra_flag = extra_flag; st.q_se0 = q_se[0]; st.q_se1 = q_se[1];
+    states[pi] = st;
+    DpJob* jobs = (DpJob*)tv.jobs;
+    for (int i = 0; i < 2; ++i) {
+        pv.n_regs[rd[i]] = n[i];
+        for (int j = 0; j < n[i]; ++j) {                        // regions whose CIGAR needs DP
+            AlnReg* p = &a[i][j];
+            p->pad_ = 0;
+            if (region_needs_dp(opt, *p)) {
+                int job = atomicAdd(tv.job_cnt, 1);
+                if (job < tv.job_cap) { DpJob jb; jb.read = rd[i]; jb.reg = j; jobs[job] = jb; p->pad_ = job + 1; }
+                else err |= ERR_JOB_CAP;
             }
         }
     }
-    if (!paired) {                                              // no_pairing
+    if (S.err | err) atomicOr(tv.err, S.err | err);
+}
+
+// mem_sam_pe, second half (one lane per pair): the records of both mates
+__global__ void k_pe_out(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3, const PeState* states, JobView jvv)
+{
+    int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= tv.n_reads >> 1) return;
+    const MemPestat pes[4] = { p0, p1, p2, p3 };
+    const JobView* jv = &jvv;
+    PeCtx c = pe_ctx(tv, pv, pi);
+    const int* rd = c.rd; const uint8_t** seq = c.seq; int* l_seq = c.l_seq; AlnReg** a = c.a; int* n = c.n; int32_t** zb = c.zb;
+    PostScratch S = post_scratch_for(tv, rd[0]);
+    OutBuf ob[2];
+    for (int i = 0; i < 2; ++i) { ob[i].p = tv.out + (size_t)rd[i] * tv.out_cap; ob[i].cap = tv.out_cap; ob[i].len = 0; ob[i].ovf = false; }
+    const PeState st = states[pi];
+    const int z[2] = { st.z0, st.z1 }, n_pri[2] = { st.n_pri0, st.n_pri1 }, q_se[2] = { st.q_se0, st.q_se1 };
+    int extra_flag = st.extra_flag;
+    if (st.paired) {
+        // records: h[i] (+ an ALT supplementary g[i]); each needs the mate's position
+        MateInfo hm[2];
+        int n_aa[2] = { 1, 1 }, alt_k[2] = { -1, -1 };
+        for (int i = 0; i < 2; ++i) {
+            AlnRec h = reg2aln(ix, opt, S, l_seq[i], seq[i], &a[i][z[i]], jv);
+            hm[i] = mate_of(h);
+            if (n_pri[i] < n[i]) {
+                const AlnReg* p = &a[i][n_pri[i]];
+                if (!(p->score < opt.T || p->secondary >= 0 || !p->is_alt)) { alt_k[i] = n_pri[i]; n_aa[i] = 2; }
+            }
+        }
+        for (int i = 0; i < 2; ++i) {
+            int32_t *cnt = 0, *has_alt = 0;
+            if (!(opt.flag & MEM_F_ALL) && n[i] > 0) {
+                cnt = zb[i]; has_alt = zb[i] + n[i];
+                if (xa_prepare(opt, n[i], a[i], cnt, has_alt) == 0) cnt = has_alt = 0;
+            }
+            AlnRec h = reg2aln(ix, opt, S, l_seq[i], seq[i], &a[i][z[i]], jv);
+            h.mapq = q_se[i];
+            h.flag |= 0x40 << i | extra_flag;
+            aln2out(ix, opt, S, ob[i], n_aa[i], 0, h, &hm[!i], l_seq[i], seq[i], n[i], a[i], cnt, has_alt, cnt ? z[i] : -1, jv);
+            if (alt_k[i] >= 0) {
+                AlnRec g = reg2aln(ix, opt, S, l_seq[i], seq[i], &a[i][alt_k[i]], jv);
+                g.flag |= 0x800 | 0x40 << i | extra_flag;
+                aln2out(ix, opt, S, ob[i], n_aa[i], 1, g, &hm[!i], l_seq[i], seq[i], n[i], a[i], cnt, has_alt, cnt ? alt_k[i] : -1, jv);
+            }
+        }
+    } else {                                                    // no_pairing
         MateInfo hm[2];
         int hrid[2];
         for (int i = 0; i < 2; ++i) {
@@ -324,7 +432,7 @@ __global__ void k_final_pe(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemP
                 if (a[i][0].score >= opt.T) which = 0;
                 else if (n_pri[i] < n[i] && a[i][n_pri[i]].score >= opt.T) which = n_pri[i];
             }
-            AlnRec h = reg2aln(ix, opt, S, l_seq[i], seq[i], which >= 0 ? &a[i][which] : 0);
+            AlnRec h = reg2aln(ix, opt, S, l_seq[i], seq[i], which >= 0 ? &a[i][which] : 0, jv);
             hm[i] = mate_of(h); hrid[i] = h.rid;
         }
         if (!(opt.flag & MEM_F_NOPAIRING) && hrid[0] == hrid[1] && hrid[0] >= 0) {
@@ -332,15 +440,14 @@ __global__ void k_final_pe(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemP
             int d = infer_dir(ix.l_pac, a[0][0].rb, a[1][0].rb, &dist);
             if (!pes[d].failed && dist >= pes[d].low && dist <= pes[d].high) extra_flag |= 2;
         }
-        reg2sam(ix, opt, S, ob[0], l_seq[0], seq[0], n[0], a[0], zb[0], 0x41 | extra_flag, &hm[1]);
-        reg2sam(ix, opt, S, ob[1], l_seq[1], seq[1], n[1], a[1], zb[1], 0x81 | extra_flag, &hm[0]);
+        reg2sam(ix, opt, S, ob[0], l_seq[0], seq[0], n[0], a[0], zb[0], 0x41 | extra_flag, &hm[1], jv);
+        reg2sam(ix, opt, S, ob[1], l_seq[1], seq[1], n[1], a[1], zb[1], 0x81 | extra_flag, &hm[0], jv);
     }
     for (int i = 0; i < 2; ++i) {
-        pv.n_regs[rd[i]] = n[i];
         tv.out_len[rd[i]] = ob[i].ovf ? 0 : ob[i].len;
         if (ob[i].ovf) atomicOr(tv.err, ERR_OUT_CAP);
     }
-    if (S.err | err) atomicOr(tv.err, S.err | err);
+    if (S.err) atomicOr(tv.err, S.err);
 }
 
 // an odd trailing read of a PE call is never processed upstream (n>>1 pairs): it produces no bytes
@@ -380,13 +487,30 @@ void launch_pe_copy_regs(hipStream_t st, const TileView& tv, const AlnReg* src, 
     if (tv.n_reads <= 0) return;
     hipLaunchKernelGGL(k_pe_copy_regs, dim3((tv.n_reads + 255) / 256), dim3(256), 0, st, tv, src, src_off, dst, dst_off, n_regs);
 }
-void launch_final_pe(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, AlnReg* regs, const int64_t* reg_off,
-                     int32_t* n_regs, int32_t* ints, void* vpool, uint8_t* scratch, int64_t scratch_per_pair, int cap_h, int cap_b, int cap_u, const MemPestat* pes)
+void launch_pe_pair(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, AlnReg* regs, const int64_t* reg_off,
+                    int32_t* n_regs, int32_t* ints, void* vpool, uint8_t* scratch, int64_t scratch_per_pair, int cap_h, int cap_b, int cap_u, const MemPestat* pes, void* states)
 {
     int np = tv.n_reads >> 1;
     hipLaunchKernelGGL(k_pe_tail, dim3(1), dim3(64), 0, st, tv);
     if (np <= 0) return;
     PeView pv; pv.regs = regs; pv.reg_off = reg_off; pv.n_regs = n_regs; pv.ints = ints; pv.vpool = vpool; pv.scratch = scratch;
     pv.scratch_per_pair = scratch_per_pair; pv.cap_h = cap_h; pv.cap_b = cap_b; pv.cap_u = cap_u;
-    hipLaunchKernelGGL(k_final_pe, dim3((np + 63) / 64), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3]);
+    // LDS of the wave-cooperative rescue SW: five stripes of cells (H0, H1, E, Hmax, query) + the row-maxima list; reads too
+    // long for 48 KB keep the scalar path
+    int cells = ((tv.max_len + 15) / 16) * 16;
+    size_t lds = (size_t)5 * cells * 4 + (size_t)cap_b * 8 + 16;
+    if (lds > 48 * 1024) { cells = 16; lds = (size_t)5 * cells * 4 + (size_t)cap_b * 8 + 16; if (lds > 48 * 1024) lds = 48 * 1024; }
+    pv.lds_cells = cells;
+    hipLaunchKernelGGL(k_pe_pair, dim3((np + 63) / 64), dim3(64), lds, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3], (PeState*)states);
 }
+void launch_pe_out(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, AlnReg* regs, const int64_t* reg_off,
+                   int32_t* n_regs, int32_t* ints, const MemPestat* pes, const void* states, const void* job_out, const uint32_t* job_cig, int cig_cap)
+{
+    int np = tv.n_reads >> 1;
+    if (np <= 0) return;
+    PeView pv; pv.vpool = 0; pv.scratch = 0; pv.scratch_per_pair = 0; pv.cap_h = pv.cap_b = pv.cap_u = 0; pv.lds_cells = 0;
+    pv.regs = regs; pv.reg_off = reg_off; pv.n_regs = n_regs; pv.ints = ints;
+    JobView jv; jv.out = (const DpOut*)job_out; jv.cig = job_cig; jv.cig_cap = cig_cap;
+    hipLaunchKernelGGL(k_pe_out, dim3((np + 63) / 64), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3], (const PeState*)states, jv);
+}
+size_t pe_state_bytes(int n_reads) { return (size_t)((n_reads >> 1) + 1) * sizeof(PeState); }

@@ -355,12 +355,13 @@ static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes
     const char* env_t = getenv("BWAMEM_HIP_TILE");
     std::vector<PeTile*> tiles;
     std::vector<int8_t> cand_dir; std::vector<int64_t> cand_is;
-    DevBuf d_dir, d_is, caps, reg_off2, regs2, ints2, vpool, pe_scratch;
+    DevBuf d_dir, d_is, caps, reg_off2, regs2, ints2, vpool, pe_scratch, pe_states;
+    int pe_job_cap = 0; size_t pe_zpool = 0;
     bool ok = false;
     int intv_cap_scale = 1, out_cap = 512;
     auto cleanup = [&]() {
         for (PeTile* t : tiles) { t->n_regs.release(); t->regs.release(); t->reg_off.release(); delete t; }
-        d_dir.release(); d_is.release(); caps.release(); reg_off2.release(); regs2.release(); ints2.release(); vpool.release(); pe_scratch.release();
+        d_dir.release(); d_is.release(); caps.release(); reg_off2.release(); regs2.release(); ints2.release(); vpool.release(); pe_scratch.release(); pe_states.release();
     };
 #define PE_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "[bwamem_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); cleanup(); return false; } } while (0)
 #define PE_REQ(cond) do { if (!(cond)) { cleanup(); return false; } } while (0)
@@ -473,15 +474,40 @@ static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes
             PE_REQ(regs2.ensure((size_t)(tot + 1) * sizeof(AlnReg)) && ints2.ensure((size_t)(tot + 1) * 8) && vpool.ensure((size_t)(tot + 2) * 16)
                    && pe_scratch.ensure((size_t)((T >> 1) + 1) * (size_t)per_pair));
             TIMED(ws, K_OTHER, launch_pe_copy_regs(ws.stream, tv, pt->regs.as<AlnReg>(), pt->reg_off.as<int64_t>(), regs2.as<AlnReg>(), reg_off2.as<int64_t>(), tv.n_regs));
-            TIMED(ws, K_FINAL, launch_final_pe(ws.stream, ix->d, opt, tv, regs2.as<AlnReg>(), reg_off2.as<int64_t>(), tv.n_regs, ints2.as<int32_t>(), vpool.p,
-                                               pe_scratch.as<uint8_t>(), per_pair, cap_h, cap_b, cap_u, pes));
+            // pairing decisions and the list of regions whose CIGAR needs DP; the DP jobs; the records
+            PE_REQ(ws.ensure_jobs(std::max(pe_job_cap, std::max(1024, T / 2)), 4 * L + 16,
+                                  std::max(pe_zpool, (size_t)std::max(pe_job_cap, std::max(1024, T / 2)) * (size_t)(2 * L + 64) * 20 + ((size_t)64 << 20))));
+            PE_REQ(pe_states.ensure(pe_state_bytes(T)));
+            {   // the job buffers may have moved
+                TileView t2 = ws.view();
+                t2.n_reads = T; t2.max_len = L; t2.read_id0 = tv.read_id0; t2.seq = tv.seq; t2.seq_off = tv.seq_off;
+                tv = t2;
+            }
+            PE_OK(hipMemsetAsync(ws.job_cnt.p, 0, 64, ws.stream));
+            TIMED(ws, K_FINAL, launch_pe_pair(ws.stream, ix->d, opt, tv, regs2.as<AlnReg>(), reg_off2.as<int64_t>(), tv.n_regs, ints2.as<int32_t>(), vpool.p,
+                                              pe_scratch.as<uint8_t>(), per_pair, cap_h, cap_b, cap_u, pes, pe_states.p));
+            int32_t n_jobs = 0, err = 0;
+            PE_OK(hipMemcpyAsync(&n_jobs, tv.job_cnt, 4, hipMemcpyDeviceToHost, ws.stream));
+            PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
+            PE_OK(hipStreamSynchronize(ws.stream));
+            if ((err & ERR_JOB_CAP) || n_jobs > ws.job_cap) { pe_job_cap = std::max(n_jobs + n_jobs / 4, ws.job_cap * 2); continue; }
+            if (err & ERR_SCRATCH) { cap_u *= 8; if (attempts < 4) continue; }
+            if (err) { fprintf(stderr, "[bwamem_hip] device error flags %d in the paired-end pairing stage\n", err); cleanup(); return false; }
+            {
+                TileView tvj = tv;                              // the job kernels address a region as regs[seed_off[read] + index]
+                tvj.regs = regs2.as<AlnReg>(); tvj.seed_off = reg_off2.as<int64_t>();
+                TIMED(ws, K_FINAL, launch_gcigar(ws.stream, ix->d, opt, tvj, n_jobs, ws.jobs.p, ws.job_out.p, ws.job_cig.as<uint32_t>(), ws.job_cig_cap,
+                                                 ws.zpool.as<uint8_t>(), (unsigned long long)ws.zpool_cap, (unsigned long long*)(ws.job_cnt.as<int32_t>() + 2)));
+            }
+            TIMED(ws, K_FINAL, launch_pe_out(ws.stream, ix->d, opt, tv, regs2.as<AlnReg>(), reg_off2.as<int64_t>(), tv.n_regs, ints2.as<int32_t>(), pes, pe_states.p,
+                                             ws.job_out.p, ws.job_cig.as<uint32_t>(), ws.job_cig_cap));
             TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.out_len, tv.out_off, T));
-            int64_t out_total = 0; int32_t err = 0;
+            int64_t out_total = 0;
             PE_OK(hipMemcpyAsync(&out_total, tv.out_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
             PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
             PE_OK(hipStreamSynchronize(ws.stream));
             if (err & ERR_OUT_CAP) { out_cap *= 4; continue; }
-            if (err & ERR_SCRATCH) { cap_u *= 8; if (attempts < 4) continue; }
+            if (err & ERR_ZPOOL) { pe_zpool = std::max(pe_zpool * 4, ws.zpool_cap * 4); continue; }
             if (err) { fprintf(stderr, "[bwamem_hip] device error flags %d in the paired-end phase 2\n", err); cleanup(); return false; }
             TileOut to; to.bytes = (size_t)out_total;
             if (out_total > 0) {

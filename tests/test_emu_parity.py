@@ -88,3 +88,18 @@ def test_emu_seed_work_queue_and_spill(emu, oracle, small_genome, monkeypatch):
     monkeypatch.setenv("BWAMEM_HIP_SEED_WPC", "1")
     monkeypatch.setenv("BWAMEM_HIP_SEED_K", "3")
     _cmp(emu, oracle, img, reads)
+
+
+def test_emu_mate_rescue_kernel_forms(emu, oracle, small_genome):
+    """wave-cooperative ksw_align2 of mate rescue: register stripes (<= 10 segments) and LDS stripes (longer mates, 16-bit mode)"""
+    seqs, img = small_genome
+    for length, ins in ((250, 600), (150, 350)):
+        pairs = B.simulate_pairs(seqs, 8, length=length, seed=40 + length, ins_mean=ins, ins_sd=30)
+        for k in (1, 6, 11):                                          # mates that do not seed: every 7th base replaced
+            pairs[k] = bytes(c if i % 7 else 65 for i, c in enumerate(pairs[k]))
+        h, ho = emu.open_index(img), oracle.open_index(img)
+        opts = B.set_opt(emu.default_options(), flag=B.MEM_F_PE)
+        req = B.pack_request(pairs)
+        pes = B.pack_pestat(ins - 150, ins + 150, float(ins), 30.0)
+        assert emu.align_raw(h, opts, req, pes) == oracle.align_raw(ho, opts, req, pes)
+        emu.destroy_index(h); oracle.destroy_index(ho)

@@ -200,9 +200,9 @@ def _parity_pe(hip, orc, img, reads, pes=None, **optkw):
         hip.destroy_index(h); orc.destroy_index(ho)
 
 
-def _damaged_pairs(seqs, n, seed):
+def _damaged_pairs(seqs, n, seed, length=100, ins_mean=300):
     import random
-    pairs = B.simulate_pairs(seqs, n, length=100, seed=seed, ins_mean=300, ins_sd=30, sub=0.01)
+    pairs = B.simulate_pairs(seqs, n, length=length, seed=seed, ins_mean=ins_mean, ins_sd=30, sub=0.01)
     rnd = random.Random(seed)
     for i in range(1, len(pairs), 6):                 # some mates too diverged to seed: mate rescue has to find them
         r = bytearray(pairs[i])
@@ -210,8 +210,17 @@ def _damaged_pairs(seqs, n, seed):
             r[k] = ord("ACGT"[rnd.randrange(4)])
         pairs[i] = bytes(r)
     for i in range(0, len(pairs), 50):                # some junk mates
-        pairs[i] = bytes(ord("ACGT"[rnd.randrange(4)]) for _ in range(100))
+        pairs[i] = bytes(ord("ACGT"[rnd.randrange(4)]) for _ in range(length))
     return pairs
+
+
+def test_parity_pe_rescue_kernel_forms(hip_lib, oracle, small_genome):
+    """mate rescue runs ksw_align2 wave-cooperatively: stripes in registers up to 10 segments (every 150 bp mate), in LDS
+    beyond; 250 bp mates take the LDS form in 16-bit mode (score range >= 250), 180 bp mates in byte mode"""
+    seqs, img = small_genome
+    _parity_pe(hip_lib, oracle, img, _damaged_pairs(seqs, 300, 11, length=250, ins_mean=600))
+    _parity_pe(hip_lib, oracle, img, _damaged_pairs(seqs, 300, 12, length=180, ins_mean=450))
+    _parity_pe(hip_lib, oracle, img, _damaged_pairs(seqs, 300, 13, length=150, ins_mean=350))
 
 
 def test_parity_pe_inferred_stats(hip_lib, oracle, small_genome):
