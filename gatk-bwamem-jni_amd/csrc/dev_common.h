@@ -137,6 +137,19 @@ DEV int ref_base2(const DevIndex& ix, int64_t p)
     return p < ix.l_pac ? pac_base(ix.pac, p) : 3 - pac_base(ix.pac, (ix.l_pac << 1) - 1 - p);
 }
 
+// ref_base2 through a one-word cache: 16 reference bases per global load for loops that walk a stretch of the reference
+struct PacCache { int64_t w; uint32_t v; };
+DEV int ref_base2_c(const DevIndex& ix, PacCache& c, int64_t p)
+{
+    const bool rev = p >= ix.l_pac;
+    const int64_t l = rev ? (ix.l_pac << 1) - 1 - p : p;
+    const int64_t w = l >> 4;
+    if (w != c.w) { c.w = w; c.v = ((const uint32_t*)ix.pac)[w]; }
+    const int k = (int)(l & 15);
+    const int b = (int)(c.v >> (((k >> 2) << 3) + 6 - ((k & 3) << 1)) & 3u);
+    return rev ? 3 - b : b;
+}
+
 DEV int64_t bns_depos(const DevIndex& ix, int64_t pos, int& is_rev)
 {
     return (is_rev = (pos >= ix.l_pac)) ? (ix.l_pac << 1) - 1 - pos : pos;

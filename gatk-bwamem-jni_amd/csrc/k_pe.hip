@@ -62,19 +62,47 @@ DEV KswR serve_sw(const DevIndex& ix, const MemOpt& opt, bool want, const SwIn& 
 {
     KswR mine; mine.score = 0; mine.te = mine.qe = mine.score2 = mine.te2 = mine.tb = mine.qb = -1;
     const int p = (xtra & KSW_XBYTE) ? 16 : 8;
-    const bool fits = ((qlen + p - 1) / p) * p <= L.cap_cells;
-    if (want && !fits) mine = sw_align2(ix, opt, I, qlen, tlen, xtra, W, err);
-    unsigned long long pend = __ballot(want && fits);
+    const int slen = (qlen + p - 1) / p;
+    const bool fits_reg = slen <= SW_REG_SEGS, fits_lds = slen * p <= L.cap_cells;
+    if (want && !fits_reg && !fits_lds) mine = sw_align2(ix, opt, I, qlen, tlen, xtra, W, err);
+    const uint64_t pm = (uint64_t)(uintptr_t)I.ms;
+    for (int mode = 1; mode <= 2; ++mode) {                 // register stripes: up to four requests of one mode at a time, one per 16-lane group
+        unsigned long long pend = __ballot(want && fits_reg && (p == 16) == (mode == 1));
+        while (pend) {
+            int s0 = 0, s1 = 0, s2 = 0, s3 = 0, cnt = 0;
+            while (pend && cnt < 4) {
+                const int b = __ffsll((long long)pend) - 1;
+                pend &= pend - 1ull;
+                if (cnt == 0) s0 = b; else if (cnt == 1) s1 = b; else if (cnt == 2) s2 = b; else s3 = b;
+                ++cnt;
+            }
+            const int g = lane >> 4;
+            const bool on = g < cnt;
+            const int src = g == 0 ? s0 : g == 1 ? s1 : g == 2 ? s2 : s3;
+            SwIn U;
+            U.ms = (const uint8_t*)(uintptr_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)(pm >> 32), src) << 32 | (uint32_t)__shfl((int)(uint32_t)pm, src));
+            U.l_ms = __shfl(I.l_ms, src); U.is_rev = __shfl(I.is_rev, src); U.qrev = 0; U.trev = 0;
+            U.t0 = (int64_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)((uint64_t)I.t0 >> 32), src) << 32 | (uint32_t)__shfl((int)(uint32_t)(uint64_t)I.t0, src));
+            const int uq = __shfl(qlen, src), ut = __shfl(tlen, src), ux = __shfl(xtra, src);
+            int e2 = 0;
+            const KswR res = sw_align2_wave4(ix, opt, U, on, mode == 1 ? 1 : 2, uq, ut, ux, L, lane, e2);
+            const int my = lane == s0 && cnt > 0 ? 0 : lane == s1 && cnt > 1 ? 1 : lane == s2 && cnt > 2 ? 2 : lane == s3 && cnt > 3 ? 3 : -1;   // the group that ran this lane's request
+            const int from = (my < 0 ? 0 : my) << 4;
+            KswR got;
+            got.score = __shfl(res.score, from); got.te = __shfl(res.te, from); got.qe = __shfl(res.qe, from); got.score2 = __shfl(res.score2, from);
+            got.te2 = __shfl(res.te2, from); got.tb = __shfl(res.tb, from); got.qb = __shfl(res.qb, from);
+            const int ge = __shfl(e2, from);
+            if (my >= 0) { mine = got; err |= ge; }
+        }
+    }
+    unsigned long long pend = __ballot(want && !fits_reg && fits_lds);      // longer mates: stripes in LDS, one request at a time
     while (pend) {
         const int src = __ffsll((long long)pend) - 1;
         pend &= pend - 1ull;
         SwIn U;
-        {
-            const uint64_t pm = (uint64_t)(uintptr_t)I.ms;
-            U.ms = (const uint8_t*)(uintptr_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)(pm >> 32), src) << 32 | (uint32_t)__shfl((int)(uint32_t)pm, src));
-            U.l_ms = __shfl(I.l_ms, src); U.is_rev = __shfl(I.is_rev, src); U.qrev = 0; U.trev = 0;
-            U.t0 = (int64_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)((uint64_t)I.t0 >> 32), src) << 32 | (uint32_t)__shfl((int)(uint32_t)(uint64_t)I.t0, src));
-        }
+        U.ms = (const uint8_t*)(uintptr_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)(pm >> 32), src) << 32 | (uint32_t)__shfl((int)(uint32_t)pm, src));
+        U.l_ms = __shfl(I.l_ms, src); U.is_rev = __shfl(I.is_rev, src); U.qrev = 0; U.trev = 0;
+        U.t0 = (int64_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)((uint64_t)I.t0 >> 32), src) << 32 | (uint32_t)__shfl((int)(uint32_t)(uint64_t)I.t0, src));
         const int uq = __shfl(qlen, src), ut = __shfl(tlen, src), ux = __shfl(xtra, src);
         int e2 = 0;
         const KswR res = sw_align2_wave(ix, opt, U, uq, ut, ux, L, lane, e2);
@@ -256,6 +284,7 @@ DEV PeCtx pe_ctx(const TileView& tv, const PeView& pv, int pi)
     return c;
 }
 
+#define PE_PAIRS_PER_WAVE 16
 // mem_sam_pe, first half (one lane per pair): mate rescue, primary marking, pairing and the mapping-quality decisions.
 // Regions whose CIGAR needs a banded global alignment are then listed as jobs for k_gcigar_lane / k_gcigar (any region of
 // either mate can end up in a record or an XA tag, so all of them are listed), and the record stage picks the results up:
@@ -265,8 +294,11 @@ __global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPe
     HIP_DYNAMIC_SHARED(int32_t, sw_lds)
     const int lane = threadIdx.x & 63;
     const int n_pairs = tv.n_reads >> 1;
-    const bool valid = (int)(blockIdx.x * blockDim.x + threadIdx.x) < n_pairs;     // lanes past the end stay for the wave-cooperative rescue
-    int pi = valid ? (int)(blockIdx.x * blockDim.x + threadIdx.x) : (n_pairs > 0 ? n_pairs - 1 : 0);
+    // PE_PAIRS_PER_WAVE pairs per wavefront, in its first lanes: the rescue alignments of a wave run one batch after another
+    // with all 64 lanes, so fewer pairs per wave means a shorter worst case; the other lanes only take part in those
+    const int slot = (int)blockIdx.x * PE_PAIRS_PER_WAVE + lane;
+    const bool valid = lane < PE_PAIRS_PER_WAVE && slot < n_pairs;
+    int pi = valid ? slot : (n_pairs > 0 ? n_pairs - 1 : 0);
     if (n_pairs <= 0) return;
     const MemPestat pes[4] = { p0, p1, p2, p3 };
     PeCtx c = pe_ctx(tv, pv, pi);
@@ -498,10 +530,10 @@ void launch_pe_pair(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const
     // LDS of the wave-cooperative rescue SW: five stripes of cells (H0, H1, E, Hmax, query) + the row-maxima list; reads too
     // long for 48 KB keep the scalar path
     int cells = ((tv.max_len + 15) / 16) * 16;
-    size_t lds = (size_t)5 * cells * 4 + (size_t)cap_b * 8 + 16;
-    if (lds > 48 * 1024) { cells = 16; lds = (size_t)5 * cells * 4 + (size_t)cap_b * 8 + 16; if (lds > 48 * 1024) lds = 48 * 1024; }
+    size_t lds = (size_t)5 * cells * 4 + (size_t)4 * cap_b * 8 + 16;          // (four row-maxima lists: up to four alignments run at once)
+    if (lds > 48 * 1024) { cells = 16; lds = (size_t)5 * cells * 4 + (size_t)4 * cap_b * 8 + 16; }
     pv.lds_cells = cells;
-    hipLaunchKernelGGL(k_pe_pair, dim3((np + 63) / 64), dim3(64), lds, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3], (PeState*)states);
+    hipLaunchKernelGGL(k_pe_pair, dim3((np + PE_PAIRS_PER_WAVE - 1) / PE_PAIRS_PER_WAVE), dim3(64), lds, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3], (PeState*)states);
 }
 void launch_pe_out(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, AlnReg* regs, const int64_t* reg_off,
                    int32_t* n_regs, int32_t* ints, const MemPestat* pes, const void* states, const void* job_out, const uint32_t* job_cig, int cig_cap)

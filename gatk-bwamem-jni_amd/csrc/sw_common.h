@@ -28,7 +28,7 @@ DEV int sat_u8(int x) { return x < 0 ? 0 : x > 255 ? 255 : x; }
 DEV int sat_i16(int x) { return x < -32768 ? -32768 : x > 32767 ? 32767 : x; }
 DEV int subs_u16(int a, int b) { int x = (int)(uint16_t)a - (int)(uint16_t)b; return x < 0 ? 0 : (int)(int16_t)(uint16_t)x; }
 
-DEV KswR sw_core(const DevIndex& ix, const MemOpt& opt, const SwIn& I, int size, int qlen, int tlen, int xtra, SwScratch& W, int& err)
+static __device__ __attribute__((noinline)) KswR sw_core(const DevIndex& ix, const MemOpt& opt, const SwIn& I, int size, int qlen, int tlen, int xtra, SwScratch& W, int& err)
 {
     const int p = 8 * (3 - size), slen = (qlen + p - 1) / p, u8 = size == 1;
     const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
@@ -147,7 +147,7 @@ struct SwLds { int32_t *H0, *H1, *E, *Hmax, *Q; uint64_t* b; int cap_cells, cap_
 
 DEV int sw_shup1(int v, int lane) { const int u = __shfl_up(v, 1); return lane == 0 ? 0 : u; }
 
-DEV KswR sw_core_wave(const DevIndex& ix, const MemOpt& opt, const SwIn& I, int size, int qlen, int tlen, int xtra, const SwLds& W, int lane, int& err)
+static __device__ __attribute__((noinline)) KswR sw_core_wave(const DevIndex& ix, const MemOpt& opt, const SwIn& I, int size, int qlen, int tlen, int xtra, const SwLds& W, int lane, int& err)
 {
     const int p = 8 * (3 - size), slen = (qlen + p - 1) / p, u8 = size == 1;
     const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
@@ -171,8 +171,9 @@ DEV KswR sw_core_wave(const DevIndex& ix, const MemOpt& opt, const SwIn& I, int 
     }
     __syncthreads();
     bool stop = false;
+    PacCache pc; pc.w = -1; pc.v = 0;
     for (int i = 0; i < tlen && !stop; ++i) {
-        const int tb = sw_t(ix, I, i);
+        const int tb = ref_base2_c(ix, pc, I.t0 + (i < I.trev ? I.trev - 1 - i : i));
         int f = 0, mx = 0;
         int h = sw_shup1(la ? H0[(slen - 1) * p + l] : 0, lane);
         for (int j = 0; j < slen; ++j) {
@@ -263,7 +264,7 @@ DEV KswR sw_core_wave(const DevIndex& ix, const MemOpt& opt, const SwIn& I, int 
 // 150 bp mate): the LDS form above is a chain of dependent LDS round trips per segment, this one is straight-line vector
 // arithmetic.  Only the row-maxima list stays in LDS.
 template <int NSEG>
-DEV KswR sw_core_wave_reg(const DevIndex& ix, const MemOpt& opt, const SwIn& I, int size, int qlen, int tlen, int xtra, const SwLds& W, int lane, int& err)
+static __device__ __attribute__((noinline)) KswR sw_core_wave_reg(const DevIndex& ix, const MemOpt& opt, const SwIn& I, int size, int qlen, int tlen, int xtra, const SwLds& W, int lane, int& err)
 {
     const int p = 8 * (3 - size), slen = (qlen + p - 1) / p, u8 = size == 1;
     const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
@@ -289,8 +290,9 @@ DEV KswR sw_core_wave_reg(const DevIndex& ix, const MemOpt& opt, const SwIn& I, 
         score_lane(ST, pad[j] ? 4 : sw_q(I, pos), sp[j], sn[j]);
     }
     bool stop = false;
+    PacCache pc; pc.w = -1; pc.v = 0;
     for (int i = 0; i < tlen && !stop; ++i) {
-        const int tb = sw_t(ix, I, i);
+        const int tb = ref_base2_c(ix, pc, I.t0 + (i < I.trev ? I.trev - 1 - i : i));
         int f = 0, mx = 0;
         int hlast = 0;
 #pragma unroll
@@ -403,3 +405,158 @@ DEV KswR sw_align2_wave(const DevIndex& ix, const MemOpt& opt, SwIn I, int qlen,
     return r;
 }
 
+
+// Up to four alignments at once, one per 16-lane group of the wavefront (upstream's 16-byte vector is exactly one group; in
+// 16-bit mode the upper 8 lanes of a group idle).  A wave that owns several pairs in need of rescue would otherwise run their
+// alignments one after another while every other wave has finished.  All arguments are per lane but uniform within a group;
+// `on` says whether the group has an alignment at all; `size` (byte or 16-bit mode) is the same for the whole wave.
+// (kept out of line: inlined into the pairing kernel its register arrays end up spilled)
+template <int NSEG>
+static __device__ __attribute__((noinline)) KswR sw_core_wave4(const DevIndex& ix, const MemOpt& opt, const SwIn& I, bool on, int size, int qlen, int tlen, int xtra, const SwLds& W, int lane, int& err)
+{
+    const int p = 8 * (3 - size), u8 = size == 1;
+    const int g = lane >> 4, sl = lane & 15;
+    const int slen = on ? (qlen + p - 1) / p : 0;
+    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    KswR r; r.score = 0; r.te = r.qe = r.score2 = r.te2 = r.tb = r.qb = -1;
+    int lo = 127, hi = 0;
+    for (int a = 0; a < 25; ++a) { if (opt.mat[a] < lo) lo = opt.mat[a]; if (opt.mat[a] > hi) hi = opt.mat[a]; }
+    const int shift = (256 - (lo & 0xff)) & 0xff, qmax = hi;
+    int n_b = 0, te = -1, gmax = 0;
+    const int minsc = (xtra & KSW_XSUBO) ? xtra & 0xffff : 0x10000;
+    const int endsc = (xtra & KSW_XSTOP) ? xtra & 0xffff : 0x10000;
+    const bool la = on && sl < p;                           // this lane is one of upstream's vector lanes of a live group
+    const int l = sl < p ? sl : 0;
+    uint64_t* const bl = W.b + (size_t)g * W.cap_b;          // the group's row-maxima list
+    const ScoreTab ST = score_tab(opt);
+    int H0[NSEG], H1[NSEG], E[NSEG], Hmax[NSEG], sn[NSEG];
+    uint32_t sp[NSEG];
+    bool pad[NSEG];
+#pragma unroll
+    for (int j = 0; j < NSEG; ++j) {
+        const int pos = j + l * slen;
+        H0[j] = H1[j] = E[j] = Hmax[j] = 0;
+        pad[j] = !(on && j < slen && pos < qlen);
+        score_lane(ST, pad[j] ? 4 : sw_q(I, pos), sp[j], sn[j]);
+    }
+    bool stop = !on;
+    PacCache pc; pc.w = -1; pc.v = 0;
+    for (int i = 0; ; ++i) {
+        const bool run = !stop && i < tlen;
+        if (__ballot(run) == 0ull) break;
+        const int tb = run ? ref_base2_c(ix, pc, I.t0 + (i < I.trev ? I.trev - 1 - i : i)) : 0;
+        int f = 0, mx = 0;
+        int hlast = 0;
+#pragma unroll
+        for (int j = 0; j < NSEG; ++j) if (j == slen - 1) hlast = H0[j];
+        int h = __shfl_up(la ? hlast : 0, 1);
+        if (sl == 0) h = 0;
+#pragma unroll
+        for (int j = 0; j < NSEG; ++j) {
+            if (run && j < slen) {
+                const int sc = (pad[j] ? 0 : score_at(sp[j], sn[j], tb)) + (u8 ? shift : 0);
+                int hh, ee = E[j], t;
+                if (u8) { hh = sat_u8(h + sc); hh = sat_u8(hh - shift); }
+                else hh = sat_i16(h + sc);
+                hh = hh > ee ? hh : ee;
+                hh = hh > f ? hh : f;
+                mx = mx > hh ? mx : hh;
+                H1[j] = hh;
+                if (u8) { ee = sat_u8(ee - e_del); t = sat_u8(hh - oe_del); }
+                else    { ee = subs_u16(ee, e_del); t = subs_u16(hh, oe_del); }
+                E[j] = ee > t ? ee : t;
+                if (u8) { f = sat_u8(f - e_ins); t = sat_u8(hh - oe_ins); }
+                else    { f = subs_u16(f, e_ins); t = subs_u16(hh, oe_ins); }
+                f = f > t ? f : t;
+                h = H0[j];
+            }
+        }
+        bool done = !run;
+        for (int k = 0; k < 16; ++k) {                      // lazy-F across segment boundaries, each group until its own fixed point
+            if (__ballot(!done) == 0ull) break;
+            int fs = __shfl_up(la ? f : 0, 1);
+            if (sl == 0) fs = 0;
+            if (!done) f = fs;
+#pragma unroll
+            for (int j = 0; j < NSEG; ++j) {
+                const bool act = !done && j < slen;
+                bool more = false;
+                if (act) {
+                    int hh = H1[j];
+                    hh = hh > f ? hh : f;
+                    H1[j] = hh;
+                    if (u8) { hh = sat_u8(hh - oe_ins); f = sat_u8(f - e_ins); more = sat_u8(f - hh) != 0; }
+                    else    { hh = subs_u16(hh, oe_ins); f = subs_u16(f, e_ins); more = f > hh; }
+                }
+                const unsigned long long bal = __ballot(la && act && more);
+                if (act && ((bal >> (g << 4)) & 0xffffull) == 0ull) done = true;
+            }
+        }
+        int imax = la && run ? mx : 0;
+        for (int o = 8; o > 0; o >>= 1) { const int u = __shfl_xor(imax, o); imax = imax > u ? imax : u; }
+        imax = __shfl(imax, g << 4);
+        if (run && imax >= minsc) {
+            if (n_b == 0 || (int32_t)bl[n_b - 1] + 1 != i) {
+                if (n_b >= W.cap_b) { err |= ERR_SCRATCH; stop = true; }
+                else { if (sl == 0) bl[n_b] = (uint64_t)imax << 32 | (uint32_t)i; ++n_b; }
+            } else if ((int)(bl[n_b - 1] >> 32) < imax) { if (sl == 0) bl[n_b - 1] = (uint64_t)imax << 32 | (uint32_t)i; }
+        }
+        __syncthreads();
+        if (run && !stop && imax > gmax) {
+            gmax = imax; te = i;
+#pragma unroll
+            for (int j = 0; j < NSEG; ++j) Hmax[j] = H1[j];
+            if (u8) { if (gmax + shift >= 255 || gmax >= endsc) stop = true; }
+            else if (gmax >= endsc) stop = true;
+        }
+        if (run) {
+#pragma unroll
+            for (int j = 0; j < NSEG; ++j) { const int t = H0[j]; H0[j] = H1[j]; H1[j] = t; }
+        }
+    }
+    __syncthreads();
+    r.score = u8 ? (gmax + shift < 255 ? gmax : 255) : gmax;
+    r.te = te;
+    {
+        int best = -1, bq = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < NSEG; ++j) {
+            if (la && j < slen) {
+                const int v = Hmax[j], pos = j + l * slen;
+                if (v > best || (v == best && pos < bq)) { best = v; bq = pos; }
+            }
+        }
+        for (int o = 8; o > 0; o >>= 1) {
+            const int ub = __shfl_xor(best, o), uq = __shfl_xor(bq, o);
+            if (ub > best || (ub == best && uq < bq)) { best = ub; bq = uq; }
+        }
+        const int qe = __shfl(bq, g << 4);
+        if (on && (!u8 || r.score != 255)) {
+            r.qe = qe;
+            if (n_b > 0) {
+                int i = (r.score + qmax - 1) / qmax;
+                int low = te - i, high = te + i;
+                for (i = 0; i < n_b; ++i) {
+                    int e = (int32_t)bl[i];
+                    if ((e < low || e > high) && (int)(bl[i] >> 32) > r.score2) { r.score2 = (int)(bl[i] >> 32); r.te2 = e; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    return r;
+}
+
+// ksw_align2 for up to four alignments (see sw_core_wave4); arguments per lane, uniform within a 16-lane group
+DEV KswR sw_align2_wave4(const DevIndex& ix, const MemOpt& opt, SwIn I, bool on, int size, int qlen, int tlen, int xtra, const SwLds& W, int lane, int& err)
+{
+    I.qrev = 0; I.trev = 0;
+    KswR r = sw_core_wave4<SW_REG_SEGS>(ix, opt, I, on, size, qlen, tlen, xtra, W, lane, err);
+    const bool again = on && !((xtra & KSW_XSTART) == 0 || ((xtra & KSW_XSUBO) && r.score < (xtra & 0xffff)));
+    if (__ballot(again) == 0ull) return r;
+    I.qrev = r.qe + 1; I.trev = r.te + 1;
+    KswR rr = sw_core_wave4<SW_REG_SEGS>(ix, opt, I, again, size, again ? r.qe + 1 : 0, tlen, KSW_XSTOP | r.score, W, lane, err);
+    if (again && r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
+    return r;
+}

@@ -8,7 +8,7 @@
 
 int main(int argc, char** argv)
 {
-    if (argc < 3) { fprintf(stderr, "usage: drive <image> <request-file> [iterations]\n"); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: drive <image> <request-file> [iterations] [extra-flag-bits]\n"); return 2; }
     int iters = argc > 3 ? atoi(argv[3]) : 1;
     int fd = open(argv[1], O_RDONLY);
     if (fd < 0) { perror(argv[1]); return 1; }
@@ -23,6 +23,7 @@ int main(int argc, char** argv)
     bwamem_batch_t* b = bwamem_hip_batch_upload(idx, req.data(), (size_t)n);
     if (!b) return 1;
     mem_opt_t* opt = jnibwa_createDefaultOptions();
+    if (argc > 4) *(int*)((char*)opt + 60) |= (int)strtol(argv[4], 0, 0);      // extra mem_opt_t.flag bits (0x2 = paired-end)
     bwamem_hip_stats_enable(1);
     for (int i = 0; i < iters; ++i)
         if (bwamem_hip_batch_align(idx, opt, 0, b, 0) != 0) { fprintf(stderr, "align failed\n"); return 1; }
