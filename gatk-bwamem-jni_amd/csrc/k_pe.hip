@@ -55,103 +55,71 @@ __global__ void k_pestat_cand(DevIndex ix, MemOpt opt, TileView tv, int8_t* cand
 }
 
 // ------------------------------------------------------------------ mate rescue (mem_matesw)
-// One ksw_align2 per requesting lane, run by the whole wavefront (sw_align2_wave); every lane of the wave calls this the
-// same number of times, `want` says whether the lane has a request.  Queries too long for the LDS stripes fall back to the
-// lane's own scalar kernel.
-DEV KswR serve_sw(const DevIndex& ix, const MemOpt& opt, bool want, const SwIn& I, int qlen, int tlen, int xtra, const SwLds& L, SwScratch& W, int lane, int& err)
-{
-    KswR mine; mine.score = 0; mine.te = mine.qe = mine.score2 = mine.te2 = mine.tb = mine.qb = -1;
-    const int p = (xtra & KSW_XBYTE) ? 16 : 8;
-    const int slen = (qlen + p - 1) / p;
-    const bool fits_reg = slen <= SW_REG_SEGS, fits_lds = slen * p <= L.cap_cells;
-    if (want && !fits_reg && !fits_lds) mine = sw_align2(ix, opt, I, qlen, tlen, xtra, W, err);
-    const uint64_t pm = (uint64_t)(uintptr_t)I.ms;
-    for (int mode = 1; mode <= 2; ++mode) {                 // register stripes: up to four requests of one mode at a time, one per 16-lane group
-        unsigned long long pend = __ballot(want && fits_reg && (p == 16) == (mode == 1));
-        while (pend) {
-            int s0 = 0, s1 = 0, s2 = 0, s3 = 0, cnt = 0;
-            while (pend && cnt < 4) {
-                const int b = __ffsll((long long)pend) - 1;
-                pend &= pend - 1ull;
-                if (cnt == 0) s0 = b; else if (cnt == 1) s1 = b; else if (cnt == 2) s2 = b; else s3 = b;
-                ++cnt;
-            }
-            const int g = lane >> 4;
-            const bool on = g < cnt;
-            const int src = g == 0 ? s0 : g == 1 ? s1 : g == 2 ? s2 : s3;
-            SwIn U;
-            U.ms = (const uint8_t*)(uintptr_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)(pm >> 32), src) << 32 | (uint32_t)__shfl((int)(uint32_t)pm, src));
-            U.l_ms = __shfl(I.l_ms, src); U.is_rev = __shfl(I.is_rev, src); U.qrev = 0; U.trev = 0;
-            U.t0 = (int64_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)((uint64_t)I.t0 >> 32), src) << 32 | (uint32_t)__shfl((int)(uint32_t)(uint64_t)I.t0, src));
-            const int uq = __shfl(qlen, src), ut = __shfl(tlen, src), ux = __shfl(xtra, src);
-            int e2 = 0;
-            const KswR res = sw_align2_wave4(ix, opt, U, on, mode == 1 ? 1 : 2, uq, ut, ux, L, lane, e2);
-            const int my = lane == s0 && cnt > 0 ? 0 : lane == s1 && cnt > 1 ? 1 : lane == s2 && cnt > 2 ? 2 : lane == s3 && cnt > 3 ? 3 : -1;   // the group that ran this lane's request
-            const int from = (my < 0 ? 0 : my) << 4;
-            KswR got;
-            got.score = __shfl(res.score, from); got.te = __shfl(res.te, from); got.qe = __shfl(res.qe, from); got.score2 = __shfl(res.score2, from);
-            got.te2 = __shfl(res.te2, from); got.tb = __shfl(res.tb, from); got.qb = __shfl(res.qb, from);
-            const int ge = __shfl(e2, from);
-            if (my >= 0) { mine = got; err |= ge; }
-        }
-    }
-    unsigned long long pend = __ballot(want && !fits_reg && fits_lds);      // longer mates: stripes in LDS, one request at a time
-    while (pend) {
-        const int src = __ffsll((long long)pend) - 1;
-        pend &= pend - 1ull;
-        SwIn U;
-        U.ms = (const uint8_t*)(uintptr_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)(pm >> 32), src) << 32 | (uint32_t)__shfl((int)(uint32_t)pm, src));
-        U.l_ms = __shfl(I.l_ms, src); U.is_rev = __shfl(I.is_rev, src); U.qrev = 0; U.trev = 0;
-        U.t0 = (int64_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)((uint64_t)I.t0 >> 32), src) << 32 | (uint32_t)__shfl((int)(uint32_t)(uint64_t)I.t0, src));
-        const int uq = __shfl(qlen, src), ut = __shfl(tlen, src), ux = __shfl(xtra, src);
-        int e2 = 0;
-        const KswR res = sw_align2_wave(ix, opt, U, uq, ut, ux, L, lane, e2);
-        if (lane == src) { mine = res; err |= e2; }
-    }
-    return mine;
-}
+// Mate rescue in three steps.  For a pair whose mate is missing from the expected window upstream runs ksw_align2 over that
+// window, anchor after anchor (up to max_matesw per end), inserting what it finds into the mate's hit list before looking
+// at the next anchor.  The alignment itself depends only on the anchor, the orientation and the mate's sequence, so
+// (1) k_pe_rescue_plan lists, per pair, every alignment the sequential procedure could ask for -- all (end, anchor,
+// orientation) whose window is not already covered by a hit *before* any rescue; hits are only ever added, so this is a
+// superset -- (2) k_pe_rescue_sw runs the listed alignments, four per wavefront, spread over the whole GPU, and
+// (3) k_pe_pair replays upstream's sequence and picks the results up.  A read with dozens of equally good hits makes
+// dozens of requests; done inside the pairing kernel they ran one after another while every other pair had long finished.
+struct RescueJob { int64_t rb; int32_t read, tag, l_ms, is_rev, tlen, xtra; };   // read: the mate (tile index); tag = end << 16 | anchor << 2 | orientation
+#define RESCUE_NOT_RUN ((int)0x81818181)     // (the byte pattern the result array is preset with)
 
-// mem_matesw for one anchor per lane; wave-uniform control (every lane passes through the same four orientations), `on`
-// says whether the lane has an anchor at all
-DEV int matesw(const DevIndex& ix, const MemOpt& opt, PostScratch& S, SwScratch& W, const SwLds& L, int lane, bool on, const MemPestat* pes, const AlnReg& a,
-               int l_ms, const uint8_t* ms, int& n_ma, AlnReg* ma, int cap_ma, int& err)
+// window and parameters of the rescue of `a`'s mate in orientation r (mem_matesw); false: no alignment for this orientation
+DEV bool rescue_req(const DevIndex& ix, const MemOpt& opt, const MemPestat* pes, const AlnReg& a, int r, int l_ms, int64_t& rb, int64_t& re, int& is_rev, int& xtra)
 {
     const int64_t l_pac = ix.l_pac;
-    int i, r, skip[4], n = 0, rid = -1;
-    for (r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
-    if (on) for (i = 0; i < n_ma; ++i) {
+    int rid = -1;
+    is_rev = (r >> 1 != (r & 1));
+    const int is_larger = !(r >> 1);
+    if (!is_rev) {
+        rb = is_larger ? a.rb + pes[r].low : a.rb - pes[r].high;
+        re = (is_larger ? a.rb + pes[r].high : a.rb - pes[r].low) + l_ms;
+    } else {
+        rb = (is_larger ? a.rb + pes[r].low : a.rb - pes[r].high) - l_ms;
+        re = is_larger ? a.rb + pes[r].high : a.rb - pes[r].low;
+    }
+    if (rb < 0) rb = 0;
+    if (re > l_pac << 1) re = l_pac << 1;
+    if (rb < re) bns_clamp(ix, rb, (rb + re) >> 1, re, rid);
+    if (!(a.rid == rid && re - rb >= opt.min_seed_len)) return false;
+    xtra = KSW_XSUBO | KSW_XSTART | (l_ms * opt.a < 250 ? KSW_XBYTE : 0) | (opt.min_seed_len * opt.a);
+    return true;
+}
+
+// orientations already covered by a hit of the mate (or without statistics)
+DEV void rescue_skip(const DevIndex& ix, const MemPestat* pes, const AlnReg& a, int n_ma, const AlnReg* ma, int skip[4])
+{
+    for (int r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
+    for (int i = 0; i < n_ma; ++i) {
         int64_t dist;
-        r = infer_dir(l_pac, a.rb, ma[i].rb, &dist);
+        const int r = infer_dir(ix.l_pac, a.rb, ma[i].rb, &dist);
         if (dist >= pes[r].low && dist <= pes[r].high) skip[r] = 1;
     }
-    if (skip[0] + skip[1] + skip[2] + skip[3] == 4) on = false;
+}
+
+// mem_matesw for one anchor; the alignments come from the job list of the pair (jobs[q .. q_end), in tag order)
+DEV int matesw(const DevIndex& ix, const MemOpt& opt, PostScratch& S, SwScratch& W, const MemPestat* pes, const AlnReg& a,
+               int l_ms, const uint8_t* ms, int& n_ma, AlnReg* ma, int cap_ma, int& err,
+               const RescueJob* jobs, const KswR* results, int& q, int q_end, int tag0)
+{
+    const int64_t l_pac = ix.l_pac;
+    int i, r, skip[4], n = 0;
+    rescue_skip(ix, pes, a, n_ma, ma, skip);
+    if (skip[0] + skip[1] + skip[2] + skip[3] == 4) return 0;
     for (r = 0; r < 4; ++r) {
-        const bool live = on && !skip[r];
-        int is_rev = (r >> 1 != (r & 1));
-        int is_larger = !(r >> 1);
-        int64_t rb = 0, re = 0;
-        bool want = false;
-        SwIn I; I.ms = ms; I.l_ms = l_ms; I.is_rev = is_rev; I.qrev = 0; I.t0 = 0; I.trev = 0;
-        int xtra = 0;
-        if (live) {
-            if (!is_rev) {
-                rb = is_larger ? a.rb + pes[r].low : a.rb - pes[r].high;
-                re = (is_larger ? a.rb + pes[r].high : a.rb - pes[r].low) + l_ms;
-            } else {
-                rb = (is_larger ? a.rb + pes[r].low : a.rb - pes[r].high) - l_ms;
-                re = is_larger ? a.rb + pes[r].high : a.rb - pes[r].low;
+        if (skip[r]) continue;
+        int is_rev, xtra;
+        int64_t rb, re;
+        if (rescue_req(ix, opt, pes, a, r, l_ms, rb, re, is_rev, xtra)) {
+            KswR aln; aln.score = RESCUE_NOT_RUN;
+            while (q < q_end && jobs[q].tag < (tag0 | r)) ++q;
+            if (q < q_end && jobs[q].tag == (tag0 | r)) aln = results[q];
+            if (aln.score == RESCUE_NOT_RUN) {                 // not listed or too long for the wave kernel: the lane's own scalar kernel
+                SwIn I; I.ms = ms; I.l_ms = l_ms; I.is_rev = is_rev; I.qrev = 0; I.t0 = rb; I.trev = 0;
+                aln = sw_align2(ix, opt, I, l_ms, (int)(re - rb), xtra, W, err);
             }
-            if (rb < 0) rb = 0;
-            if (re > l_pac << 1) re = l_pac << 1;
-            if (rb < re) bns_clamp(ix, rb, (rb + re) >> 1, re, rid);
-            if (a.rid == rid && re - rb >= opt.min_seed_len) {
-                want = true;
-                xtra = KSW_XSUBO | KSW_XSTART | (l_ms * opt.a < 250 ? KSW_XBYTE : 0) | (opt.min_seed_len * opt.a);
-                I.t0 = rb;
-            }
-        }
-        const KswR aln = serve_sw(ix, opt, want, I, l_ms, (int)(re - rb), xtra, L, W, lane, err);
-        if (want) {
             if (aln.score >= opt.min_seed_len && aln.qb >= 0) {
                 AlnReg b;
                 b.rb = b.re = 0; b.qb = b.qe = 0; b.rid = 0; b.score = b.truesc = b.sub = b.alt_sc = b.csub = b.sub_n = b.w = b.seedcov = 0;
@@ -166,18 +134,16 @@ DEV int matesw(const DevIndex& ix, const MemOpt& opt, PostScratch& S, SwScratch&
                 b.csub = aln.score2;
                 b.secondary = -1;
                 b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
-                if (n_ma >= cap_ma) { err |= ERR_SCRATCH; on = false; }
-                else {
-                    ++n_ma;
-                    for (i = 0; i < n_ma - 1; ++i) if (ma[i].score < b.score) break;
-                    int tmp = i;
-                    for (i = n_ma - 1; i > tmp; --i) ma[i] = ma[i - 1];
-                    ma[i] = b;
-                }
+                if (n_ma >= cap_ma) { err |= ERR_SCRATCH; return n; }
+                ++n_ma;
+                for (i = 0; i < n_ma - 1; ++i) if (ma[i].score < b.score) break;
+                int tmp = i;
+                for (i = n_ma - 1; i > tmp; --i) ma[i] = ma[i - 1];
+                ma[i] = b;
             }
             ++n;
         }
-        if (on && !skip[r] && n) n_ma = sort_dedup_patch(ix, opt, S, 0, n_ma, ma);
+        if (n) n_ma = sort_dedup_patch(ix, opt, S, 0, n_ma, ma);
     }
     return n;
 }
@@ -259,7 +225,6 @@ struct PeView {
     int64_t scratch_per_pair;
     void* vpool;              // Pair64 per region slot (indexed by reg_off of the pair's first read)
     int cap_h, cap_b, cap_u;
-    int lds_cells;            // k_pe_pair: cells per LDS stripe of the wave-cooperative rescue SW
 };
 
 // what the pairing stage decides for one pair and the record stage needs back
@@ -284,64 +249,137 @@ DEV PeCtx pe_ctx(const TileView& tv, const PeView& pv, int pi)
     return c;
 }
 
-#define PE_PAIRS_PER_WAVE 16
-// mem_sam_pe, first half (one lane per pair): mate rescue, primary marking, pairing and the mapping-quality decisions.
+// per-pair scratch of the pairing stage: the scalar SW arrays, the rescue anchors of both ends, mem_pair's u array
+struct PeScratch { SwScratch W; AlnReg* anchors[2]; Pair64* u; };
+DEV PeScratch pe_scratch(const MemOpt& opt, const PeView& pv, int pi)
+{
+    PeScratch P;
+    uint8_t* sp = pv.scratch + (size_t)pi * pv.scratch_per_pair;
+    P.W.cap_h = pv.cap_h; P.W.cap_b = pv.cap_b;
+    P.W.H0 = (int32_t*)sp; sp += (size_t)P.W.cap_h * 4; P.W.H1 = (int32_t*)sp; sp += (size_t)P.W.cap_h * 4;
+    P.W.E = (int32_t*)sp; sp += (size_t)P.W.cap_h * 4; P.W.Hmax = (int32_t*)sp; sp += (size_t)P.W.cap_h * 4;
+    P.W.b = (uint64_t*)sp; sp += (size_t)P.W.cap_b * 8;
+    P.anchors[0] = (AlnReg*)sp; sp += (size_t)opt.max_matesw * sizeof(AlnReg);
+    P.anchors[1] = (AlnReg*)sp; sp += (size_t)opt.max_matesw * sizeof(AlnReg);
+    P.u = (Pair64*)sp;
+    return P;
+}
+// the rescue anchors of both ends: hits within pen_unpaired of the best (copies: the hit lists change during rescue)
+DEV void pe_anchors(const MemOpt& opt, const PeCtx& c, PeScratch& P, int n_anch[2])
+{
+    for (int i = 0; i < 2; ++i) {
+        n_anch[i] = 0;
+        for (int j = 0; j < c.n[i]; ++j)
+            if (c.a[i][j].score >= c.a[i][0].score - opt.pen_unpaired) { if (n_anch[i] < opt.max_matesw) P.anchors[i][n_anch[i]] = c.a[i][j]; ++n_anch[i]; }
+    }
+}
+
+// mate rescue, step 1 (one lane per pair): list the alignments the rescue of this pair may ask for
+__global__ void k_pe_rescue_plan(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3,
+                                 RescueJob* jobs, int32_t* job_first, int32_t* job_num, int32_t* counter, int cap)
+{
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= tv.n_reads >> 1) return;
+    const MemPestat pes[4] = { p0, p1, p2, p3 };
+    PeCtx c = pe_ctx(tv, pv, pi);
+    PeScratch P = pe_scratch(opt, pv, pi);
+    int n_anch[2];
+    pe_anchors(opt, c, P, n_anch);
+    int first = 0, cnt = 0;
+    for (int pass = 0; pass < 2; ++pass) {                      // count, reserve, write
+        int k = 0;
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < n_anch[i] && j < opt.max_matesw; ++j) {
+                const AlnReg anc = P.anchors[i][j];
+                int skip[4];
+                rescue_skip(ix, pes, anc, c.n[!i], c.a[!i], skip);
+                for (int r = 0; r < 4; ++r) {
+                    if (skip[r]) continue;
+                    int is_rev, xtra; int64_t rb, re;
+                    if (!rescue_req(ix, opt, pes, anc, r, c.l_seq[!i], rb, re, is_rev, xtra)) continue;
+                    if (pass == 1 && k < cnt) {
+                        RescueJob jb; jb.rb = rb; jb.read = c.rd[!i]; jb.tag = i << 16 | j << 2 | r; jb.l_ms = c.l_seq[!i]; jb.is_rev = is_rev; jb.tlen = (int)(re - rb); jb.xtra = xtra;
+                        jobs[first + k] = jb;
+                    }
+                    ++k;
+                }
+            }
+        if (pass == 0) {
+            cnt = k;
+            if (cnt > 0) {
+                first = atomicAdd(counter, cnt);
+                if (first + cnt > cap) { atomicOr(tv.err, ERR_JOB_CAP); cnt = 0; }
+            }
+            if (cnt == 0) break;
+        }
+    }
+    job_first[pi] = first; job_num[pi] = cnt;
+}
+
+// mate rescue, step 2: ksw_align2 for the listed alignments, four per wavefront (one per 16-lane group, sw_common.h).
+// Instantiated for queries of up to 10 segments (150 bp mates) and up to 32 (250 bp mates in 16-bit mode); an instance
+// leaves the jobs outside (LO, NSEG] segments alone.
+template <int LO, int NSEG>
+__global__ void __launch_bounds__(64) k_pe_rescue_sw(DevIndex ix, MemOpt opt, TileView tv, const RescueJob* jobs, const int32_t* counter, int cap, KswR* results, int cap_b)
+{
+    HIP_DYNAMIC_SHARED(uint64_t, blists)
+    const int lane = threadIdx.x;
+    const int n = *counter < cap ? *counter : cap;
+    if ((int)blockIdx.x * 4 >= n) return;
+    const int job = blockIdx.x * 4 + (lane >> 4);
+    const bool on = job < n;
+    RescueJob jb; jb.rb = 0; jb.read = 0; jb.tag = 0; jb.l_ms = 0; jb.is_rev = 0; jb.tlen = 0; jb.xtra = 0;
+    if (on) jb = jobs[job];
+    SwLds L; L.b = blists; L.cap_b = cap_b;
+    SwIn I; I.ms = tv.seq + tv.seq_off[jb.read]; I.l_ms = jb.l_ms; I.is_rev = jb.is_rev; I.qrev = 0; I.t0 = jb.rb; I.trev = 0;
+    const bool u8 = (jb.xtra & KSW_XBYTE) != 0;
+    const int p = u8 ? 16 : 8;
+    const int slen = (jb.l_ms + p - 1) / p;
+    const bool fits = on && slen > LO && slen <= NSEG;
+    if (__ballot(fits) == 0ull) return;
+    KswR res; res.score = RESCUE_NOT_RUN; res.te = res.qe = res.score2 = res.te2 = res.tb = res.qb = -1;
+    int err = 0;
+    for (int mode = 1; mode <= 2; ++mode) {                     // byte-mode groups, then 16-bit-mode groups
+        const bool mine = fits && u8 == (mode == 1);
+        if (__ballot(mine) == 0ull) continue;
+        const KswR rr = sw_align2_wave4<NSEG>(ix, opt, I, mine, mode == 1 ? 1 : 2, jb.l_ms, jb.tlen, jb.xtra, L, lane, err);
+        if (mine) res = rr;
+    }
+    if (fits && (lane & 15) == 0) results[job] = res;
+    if (err) atomicOr(tv.err, err);
+}
+
+// mem_sam_pe, first half (one lane per pair): mate rescue (step 3: upstream's sequence with the alignments precomputed),
+// primary marking, pairing and the mapping-quality decisions.
 // Regions whose CIGAR needs a banded global alignment are then listed as jobs for k_gcigar_lane / k_gcigar (any region of
 // either mate can end up in a record or an XA tag, so all of them are listed), and the record stage picks the results up:
 // a one-lane DP inside this kernel would stall the other 63 pairs of the wave.
-__global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3, PeState* states)
+__global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3, PeState* states,
+                          const RescueJob* rjobs, const KswR* rres, const int32_t* job_first, const int32_t* job_num)
 {
-    HIP_DYNAMIC_SHARED(int32_t, sw_lds)
-    const int lane = threadIdx.x & 63;
-    const int n_pairs = tv.n_reads >> 1;
-    // PE_PAIRS_PER_WAVE pairs per wavefront, in its first lanes: the rescue alignments of a wave run one batch after another
-    // with all 64 lanes, so fewer pairs per wave means a shorter worst case; the other lanes only take part in those
-    const int slot = (int)blockIdx.x * PE_PAIRS_PER_WAVE + lane;
-    const bool valid = lane < PE_PAIRS_PER_WAVE && slot < n_pairs;
-    int pi = valid ? slot : (n_pairs > 0 ? n_pairs - 1 : 0);
-    if (n_pairs <= 0) return;
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= tv.n_reads >> 1) return;
     const MemPestat pes[4] = { p0, p1, p2, p3 };
     PeCtx c = pe_ctx(tv, pv, pi);
     const int* rd = c.rd; const uint8_t** seq = c.seq; int* l_seq = c.l_seq; AlnReg** a = c.a; int* n = c.n; int* cap = c.cap; int32_t** zb = c.zb;
     PostScratch S = post_scratch_for(tv, rd[0]);
     int err = 0;
-    SwLds L;                                                // stripes of the wave-cooperative mate rescue
-    L.cap_cells = pv.lds_cells; L.cap_b = pv.cap_b;
-    L.H0 = sw_lds; L.H1 = L.H0 + L.cap_cells; L.E = L.H1 + L.cap_cells; L.Hmax = L.E + L.cap_cells; L.Q = L.Hmax + L.cap_cells;
-    L.b = (uint64_t*)(L.Q + L.cap_cells);
-    // scratch carve-up
-    uint8_t* sp = pv.scratch + (size_t)pi * pv.scratch_per_pair;
-    SwScratch W;
-    W.cap_h = pv.cap_h; W.cap_b = pv.cap_b;
-    W.H0 = (int32_t*)sp; sp += (size_t)W.cap_h * 4; W.H1 = (int32_t*)sp; sp += (size_t)W.cap_h * 4;
-    W.E = (int32_t*)sp; sp += (size_t)W.cap_h * 4; W.Hmax = (int32_t*)sp; sp += (size_t)W.cap_h * 4;
-    W.b = (uint64_t*)sp; sp += (size_t)W.cap_b * 8;
-    AlnReg* anchors[2]; int n_anch[2];
-    anchors[0] = (AlnReg*)sp; sp += (size_t)opt.max_matesw * sizeof(AlnReg);
-    anchors[1] = (AlnReg*)sp; sp += (size_t)opt.max_matesw * sizeof(AlnReg);
+    PeScratch P = pe_scratch(opt, pv, pi);
     Pair64* v = (Pair64*)pv.vpool + pv.reg_off[rd[0]];      // cap[0] + cap[1] entries >= n_pri[0] + n_pri[1]
-    Pair64* u = (Pair64*)sp;
+    Pair64* u = P.u;
     const int cap_u = pv.cap_u;
 
     const uint64_t id = (uint64_t)((tv.read_id0 >> 1) + pi);
     int z[2] = { 0, 0 }, o = 0, subo = 0, n_sub = 0, extra_flag = 1, n_pri[2], q_se[2] = { 0, 0 };
     if (!(opt.flag & MEM_F_NO_RESCUE)) {                       // mate rescue from the best hits of each end
-        for (int i = 0; i < 2; ++i) {
-            n_anch[i] = 0;
-            if (valid) for (int j = 0; j < n[i]; ++j)
-                if (a[i][j].score >= a[i][0].score - opt.pen_unpaired) { if (n_anch[i] < opt.max_matesw) anchors[i][n_anch[i]] = a[i][j]; ++n_anch[i]; }
-        }
-        for (int i = 0; i < 2; ++i) {                          // the wave walks the anchors together: the rescue SW is wave-cooperative
-            const int mine = n_anch[i] < opt.max_matesw ? n_anch[i] : opt.max_matesw;
-            const int most = wave_max(mine);
-            for (int j = 0; j < most; ++j) {
-                AlnReg anc;
-                if (j < mine) anc = anchors[i][j]; else { anc = a[0][0]; }
-                matesw(ix, opt, S, W, L, lane, j < mine, pes, anc, l_seq[!i], seq[!i], n[!i], a[!i], cap[!i], err);
-            }
-        }
+        int n_anch[2];
+        pe_anchors(opt, c, P, n_anch);
+        int q = job_first[pi];
+        const int q_end = q + job_num[pi];
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < n_anch[i] && j < opt.max_matesw; ++j)
+                matesw(ix, opt, S, P.W, pes, P.anchors[i][j], l_seq[!i], seq[!i], n[!i], a[!i], cap[!i], err, rjobs, rres, q, q_end, i << 16 | j << 2);
     }
-    if (!valid) return;
     n_pri[0] = mark_primary_se(opt, n[0], a[0], (int64_t)(id << 1 | 0), zb[0]);
     n_pri[1] = mark_primary_se(opt, n[1], a[1], (int64_t)(id << 1 | 1), zb[1]);
     if (opt.flag & MEM_F_PRIMARY5) { reorder_primary5(opt.T, n[0], a[0]); reorder_primary5(opt.T, n[1], a[1]); }
@@ -519,28 +557,37 @@ void launch_pe_copy_regs(hipStream_t st, const TileView& tv, const AlnReg* src, 
     if (tv.n_reads <= 0) return;
     hipLaunchKernelGGL(k_pe_copy_regs, dim3((tv.n_reads + 255) / 256), dim3(256), 0, st, tv, src, src_off, dst, dst_off, n_regs);
 }
+// mate rescue steps 1 and 2 + the pairing stage.  rescue: RescueJob[cap], KswR[cap], per-pair first/count, a counter (zeroed here)
 void launch_pe_pair(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, AlnReg* regs, const int64_t* reg_off,
-                    int32_t* n_regs, int32_t* ints, void* vpool, uint8_t* scratch, int64_t scratch_per_pair, int cap_h, int cap_b, int cap_u, const MemPestat* pes, void* states)
+                    int32_t* n_regs, int32_t* ints, void* vpool, uint8_t* scratch, int64_t scratch_per_pair, int cap_h, int cap_b, int cap_u, const MemPestat* pes, void* states,
+                    void* rescue_jobs, void* rescue_res, int32_t* rescue_first, int32_t* rescue_num, int32_t* rescue_cnt, int rescue_cap)
 {
     int np = tv.n_reads >> 1;
     hipLaunchKernelGGL(k_pe_tail, dim3(1), dim3(64), 0, st, tv);
     if (np <= 0) return;
     PeView pv; pv.regs = regs; pv.reg_off = reg_off; pv.n_regs = n_regs; pv.ints = ints; pv.vpool = vpool; pv.scratch = scratch;
     pv.scratch_per_pair = scratch_per_pair; pv.cap_h = cap_h; pv.cap_b = cap_b; pv.cap_u = cap_u;
-    // LDS of the wave-cooperative rescue SW: five stripes of cells (H0, H1, E, Hmax, query) + the row-maxima list; reads too
-    // long for 48 KB keep the scalar path
-    int cells = ((tv.max_len + 15) / 16) * 16;
-    size_t lds = (size_t)5 * cells * 4 + (size_t)4 * cap_b * 8 + 16;          // (four row-maxima lists: up to four alignments run at once)
-    if (lds > 48 * 1024) { cells = 16; lds = (size_t)5 * cells * 4 + (size_t)4 * cap_b * 8 + 16; }
-    pv.lds_cells = cells;
-    hipLaunchKernelGGL(k_pe_pair, dim3((np + PE_PAIRS_PER_WAVE - 1) / PE_PAIRS_PER_WAVE), dim3(64), lds, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3], (PeState*)states);
+    (void)hipMemsetAsync(rescue_cnt, 0, 4, st);
+    if (!(opt.flag & MEM_F_NO_RESCUE)) {
+        hipLaunchKernelGGL(k_pe_rescue_plan, dim3((np + 127) / 128), dim3(128), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3],
+                           (RescueJob*)rescue_jobs, rescue_first, rescue_num, rescue_cnt, rescue_cap);
+        (void)hipMemsetAsync(rescue_res, 0x81, pe_rescue_bytes(1, rescue_cap), st);          // every score = RESCUE_NOT_RUN until an instance writes it
+        hipLaunchKernelGGL((k_pe_rescue_sw<0, 10>), dim3((rescue_cap + 3) / 4), dim3(64), (size_t)4 * cap_b * 8, st, ix, opt, tv, (const RescueJob*)rescue_jobs, (const int32_t*)rescue_cnt, rescue_cap,
+                           (KswR*)rescue_res, cap_b);
+        if (tv.max_len > 80)
+            hipLaunchKernelGGL((k_pe_rescue_sw<10, 32>), dim3((rescue_cap + 3) / 4), dim3(64), (size_t)4 * cap_b * 8, st, ix, opt, tv, (const RescueJob*)rescue_jobs, (const int32_t*)rescue_cnt, rescue_cap,
+                               (KswR*)rescue_res, cap_b);
+    }
+    hipLaunchKernelGGL(k_pe_pair, dim3((np + 63) / 64), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3], (PeState*)states,
+                       (const RescueJob*)rescue_jobs, (const KswR*)rescue_res, (const int32_t*)rescue_first, (const int32_t*)rescue_num);
 }
+size_t pe_rescue_bytes(int what, int cap) { return what == 0 ? (size_t)cap * sizeof(RescueJob) : (size_t)cap * sizeof(KswR); }
 void launch_pe_out(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, AlnReg* regs, const int64_t* reg_off,
                    int32_t* n_regs, int32_t* ints, const MemPestat* pes, const void* states, const void* job_out, const uint32_t* job_cig, int cig_cap)
 {
     int np = tv.n_reads >> 1;
     if (np <= 0) return;
-    PeView pv; pv.vpool = 0; pv.scratch = 0; pv.scratch_per_pair = 0; pv.cap_h = pv.cap_b = pv.cap_u = 0; pv.lds_cells = 0;
+    PeView pv; pv.vpool = 0; pv.scratch = 0; pv.scratch_per_pair = 0; pv.cap_h = pv.cap_b = pv.cap_u = 0;
     pv.regs = regs; pv.reg_off = reg_off; pv.n_regs = n_regs; pv.ints = ints;
     JobView jv; jv.out = (const DpOut*)job_out; jv.cig = job_cig; jv.cig_cap = cig_cap;
     hipLaunchKernelGGL(k_pe_out, dim3((np + 63) / 64), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3], (const PeState*)states, jv);

@@ -355,13 +355,13 @@ static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes
     const char* env_t = getenv("BWAMEM_HIP_TILE");
     std::vector<PeTile*> tiles;
     std::vector<int8_t> cand_dir; std::vector<int64_t> cand_is;
-    DevBuf d_dir, d_is, caps, reg_off2, regs2, ints2, vpool, pe_scratch, pe_states;
-    int pe_job_cap = 0; size_t pe_zpool = 0;
+    DevBuf d_dir, d_is, caps, reg_off2, regs2, ints2, vpool, pe_scratch, pe_states, rescue[3];
+    int pe_job_cap = 0, pe_rescue_cap = 0; size_t pe_zpool = 0;
     bool ok = false;
     int intv_cap_scale = 1, out_cap = 512;
     auto cleanup = [&]() {
         for (PeTile* t : tiles) { t->n_regs.release(); t->regs.release(); t->reg_off.release(); delete t; }
-        d_dir.release(); d_is.release(); caps.release(); reg_off2.release(); regs2.release(); ints2.release(); vpool.release(); pe_scratch.release(); pe_states.release();
+        d_dir.release(); d_is.release(); caps.release(); reg_off2.release(); regs2.release(); ints2.release(); vpool.release(); pe_scratch.release(); pe_states.release(); rescue[0].release(); rescue[1].release(); rescue[2].release();
     };
 #define PE_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "[bwamem_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); cleanup(); return false; } } while (0)
 #define PE_REQ(cond) do { if (!(cond)) { cleanup(); return false; } } while (0)
@@ -484,12 +484,21 @@ static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes
                 tv = t2;
             }
             PE_OK(hipMemsetAsync(ws.job_cnt.p, 0, 64, ws.stream));
+            {   // rescue alignments: a few per cent of the pairs ask for one, pairs in repeats for many
+                const int rc = std::max(pe_rescue_cap, std::max(4096, T / 8));
+                PE_REQ(rescue[0].ensure(pe_rescue_bytes(0, rc)) && rescue[1].ensure(pe_rescue_bytes(1, rc)) && rescue[2].ensure((size_t)(T / 2 + 1) * 8 + 64));
+                pe_rescue_cap = rc;
+            }
             TIMED(ws, K_FINAL, launch_pe_pair(ws.stream, ix->d, opt, tv, regs2.as<AlnReg>(), reg_off2.as<int64_t>(), tv.n_regs, ints2.as<int32_t>(), vpool.p,
-                                              pe_scratch.as<uint8_t>(), per_pair, cap_h, cap_b, cap_u, pes, pe_states.p));
+                                              pe_scratch.as<uint8_t>(), per_pair, cap_h, cap_b, cap_u, pes, pe_states.p,
+                                              rescue[0].p, rescue[1].p, rescue[2].as<int32_t>() + 16, rescue[2].as<int32_t>() + 16 + (T / 2 + 1), rescue[2].as<int32_t>(), pe_rescue_cap));
             int32_t n_jobs = 0, err = 0;
             PE_OK(hipMemcpyAsync(&n_jobs, tv.job_cnt, 4, hipMemcpyDeviceToHost, ws.stream));
             PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
             PE_OK(hipStreamSynchronize(ws.stream));
+            int32_t n_rescue = 0;
+            PE_OK(hipMemcpy(&n_rescue, rescue[2].p, 4, hipMemcpyDeviceToHost));
+            if (n_rescue > pe_rescue_cap) { pe_rescue_cap = n_rescue + n_rescue / 4; continue; }
             if ((err & ERR_JOB_CAP) || n_jobs > ws.job_cap) { pe_job_cap = std::max(n_jobs + n_jobs / 4, ws.job_cap * 2); continue; }
             if (err & ERR_SCRATCH) { cap_u *= 8; if (attempts < 4) continue; }
             if (err) { fprintf(stderr, "[bwamem_hip] device error flags %d in the paired-end pairing stage\n", err); cleanup(); return false; }

@@ -136,281 +136,18 @@ DEV KswR sw_align2(const DevIndex& ix, const MemOpt& opt, SwIn I, int qlen, int 
 }
 
 
-// ------------------------------------------------------------------ the same kernel, one wavefront per alignment
-// Mate rescue runs in a one-lane-per-pair kernel; a rescue is rare (a mate missing from its window) but a scalar
-// ksw_align2 over a ~600-base window with its arrays in global memory takes ~0.4 s of dependent round trips, and every
-// pair in the kernel waits for the slowest.  Here the wave that owns the pair runs the alignment together: upstream's
-// SSE2 lane k (16 bytes or 8 shorts per vector) is wavefront lane k, the segment loop and the lazy-F loop are the
-// sequential dimension exactly as upstream has them, and the H/E/Hmax stripes, the query profile and the row-maxima
-// list live in LDS.  Every call argument is wave-uniform; so is the result.
-struct SwLds { int32_t *H0, *H1, *E, *Hmax, *Q; uint64_t* b; int cap_cells, cap_b; };   // Q: query code per cell (5 = padding)
-
-DEV int sw_shup1(int v, int lane) { const int u = __shfl_up(v, 1); return lane == 0 ? 0 : u; }
-
-static __device__ __attribute__((noinline)) KswR sw_core_wave(const DevIndex& ix, const MemOpt& opt, const SwIn& I, int size, int qlen, int tlen, int xtra, const SwLds& W, int lane, int& err)
-{
-    const int p = 8 * (3 - size), slen = (qlen + p - 1) / p, u8 = size == 1;
-    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
-    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    KswR r; r.score = 0; r.te = r.qe = r.score2 = r.te2 = r.tb = r.qb = -1;
-    if (slen * p > W.cap_cells) { err |= ERR_SCRATCH; return r; }
-    int lo = 127, hi = 0;
-    for (int a = 0; a < 25; ++a) { if (opt.mat[a] < lo) lo = opt.mat[a]; if (opt.mat[a] > hi) hi = opt.mat[a]; }
-    const int shift = (256 - (lo & 0xff)) & 0xff, qmax = hi;
-    int n_b = 0, te = -1, gmax = 0;
-    const int minsc = (xtra & KSW_XSUBO) ? xtra & 0xffff : 0x10000;
-    const int endsc = (xtra & KSW_XSTOP) ? xtra & 0xffff : 0x10000;
-    const bool la = lane < p;                              // this wavefront lane is one of upstream's vector lanes
-    const int l = la ? lane : 0;
-    int32_t *H0 = W.H0, *H1 = W.H1, *E = W.E, *Hmax = W.Hmax;
-    const ScoreTab ST = score_tab(opt);
-    if (la) for (int j = 0; j < slen; ++j) {
-        const int pos = j + l * slen;
-        E[j * p + l] = 0; H0[j * p + l] = 0; Hmax[j * p + l] = 0;
-        W.Q[j * p + l] = pos >= qlen ? 5 : sw_q(I, pos);
-    }
-    __syncthreads();
-    bool stop = false;
-    PacCache pc; pc.w = -1; pc.v = 0;
-    for (int i = 0; i < tlen && !stop; ++i) {
-        const int tb = ref_base2_c(ix, pc, I.t0 + (i < I.trev ? I.trev - 1 - i : i));
-        int f = 0, mx = 0;
-        int h = sw_shup1(la ? H0[(slen - 1) * p + l] : 0, lane);
-        for (int j = 0; j < slen; ++j) {
-            if (la) {
-                const int q = W.Q[j * p + l];
-                uint32_t sp; int sn;
-                score_lane(ST, q < 5 ? q : 4, sp, sn);
-                const int sc = (q == 5 ? 0 : score_at(sp, sn, tb)) + (u8 ? shift : 0);
-                int hh, ee = E[j * p + l], t;
-                if (u8) { hh = sat_u8(h + sc); hh = sat_u8(hh - shift); }
-                else hh = sat_i16(h + sc);
-                hh = hh > ee ? hh : ee;
-                hh = hh > f ? hh : f;
-                mx = mx > hh ? mx : hh;
-                H1[j * p + l] = hh;
-                if (u8) { ee = sat_u8(ee - e_del); t = sat_u8(hh - oe_del); }
-                else    { ee = subs_u16(ee, e_del); t = subs_u16(hh, oe_del); }
-                ee = ee > t ? ee : t;
-                E[j * p + l] = ee;
-                if (u8) { f = sat_u8(f - e_ins); t = sat_u8(hh - oe_ins); }
-                else    { f = subs_u16(f, e_ins); t = subs_u16(hh, oe_ins); }
-                f = f > t ? f : t;
-                h = H0[j * p + l];
-            }
-        }
-        bool done = false;
-        for (int k = 0; k < 16 && !done; ++k) {            // lazy-F across segment boundaries
-            f = sw_shup1(la ? f : 0, lane);
-            for (int j = 0; j < slen; ++j) {
-                bool more = false;
-                if (la) {
-                    int hh = H1[j * p + l];
-                    hh = hh > f ? hh : f;
-                    H1[j * p + l] = hh;
-                    if (u8) { hh = sat_u8(hh - oe_ins); f = sat_u8(f - e_ins); more = sat_u8(f - hh) != 0; }
-                    else    { hh = subs_u16(hh, oe_ins); f = subs_u16(f, e_ins); more = f > hh; }
-                }
-                if (__ballot(more) == 0ull) { done = true; break; }
-            }
-        }
-        int imax = la ? mx : 0;
-        for (int o = 8; o > 0; o >>= 1) { const int u = __shfl_xor(imax, o); imax = imax > u ? imax : u; }   // lanes 0..15 hold the vector lanes
-        imax = __shfl(imax, 0);
-        if (imax >= minsc) {                               // the list of row maxima (uniform bookkeeping, one writer)
-            if (n_b == 0 || (int32_t)W.b[n_b - 1] + 1 != i) {
-                if (n_b >= W.cap_b) { err |= ERR_SCRATCH; return r; }
-                if (lane == 0) W.b[n_b] = (uint64_t)imax << 32 | (uint32_t)i;
-                ++n_b;
-            } else if ((int)(W.b[n_b - 1] >> 32) < imax) { if (lane == 0) W.b[n_b - 1] = (uint64_t)imax << 32 | (uint32_t)i; }
-            __syncthreads();
-        }
-        if (imax > gmax) {
-            gmax = imax; te = i;
-            if (la) for (int j = 0; j < slen; ++j) Hmax[j * p + l] = H1[j * p + l];
-            if (u8) { if (gmax + shift >= 255 || gmax >= endsc) stop = true; }
-            else if (gmax >= endsc) stop = true;
-        }
-        int32_t* S = H1; H1 = H0; H0 = S;
-    }
-    __syncthreads();
-    r.score = u8 ? (gmax + shift < 255 ? gmax : 255) : gmax;
-    r.te = te;
-    if (!u8 || r.score != 255) {
-        int best = -1, bq = 0x7fffffff;                    // maximum of Hmax; among equal cells the smallest query position
-        if (la) for (int j = 0; j < slen; ++j) {
-            const int v = Hmax[j * p + l], pos = j + l * slen;
-            if (v > best || (v == best && pos < bq)) { best = v; bq = pos; }
-        }
-        for (int o = 8; o > 0; o >>= 1) {
-            const int ub = __shfl_xor(best, o), uq = __shfl_xor(bq, o);
-            if (ub > best || (ub == best && uq < bq)) { best = ub; bq = uq; }
-        }
-        r.qe = __shfl(bq, 0);
-        if (n_b > 0) {
-            int i = (r.score + qmax - 1) / qmax;
-            int low = te - i, high = te + i;
-            for (i = 0; i < n_b; ++i) {
-                int e = (int32_t)W.b[i];
-                if ((e < low || e > high) && (int)(W.b[i] >> 32) > r.score2) { r.score2 = (int)(W.b[i] >> 32); r.te2 = e; }
-            }
-        }
-    }
-    __syncthreads();
-    return r;
-}
-
-// The same again with the stripes in registers, for queries of at most NSEG segments (16 x NSEG bases in byte mode: every
-// 150 bp mate): the LDS form above is a chain of dependent LDS round trips per segment, this one is straight-line vector
-// arithmetic.  Only the row-maxima list stays in LDS.
-template <int NSEG>
-static __device__ __attribute__((noinline)) KswR sw_core_wave_reg(const DevIndex& ix, const MemOpt& opt, const SwIn& I, int size, int qlen, int tlen, int xtra, const SwLds& W, int lane, int& err)
-{
-    const int p = 8 * (3 - size), slen = (qlen + p - 1) / p, u8 = size == 1;
-    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
-    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    KswR r; r.score = 0; r.te = r.qe = r.score2 = r.te2 = r.tb = r.qb = -1;
-    int lo = 127, hi = 0;
-    for (int a = 0; a < 25; ++a) { if (opt.mat[a] < lo) lo = opt.mat[a]; if (opt.mat[a] > hi) hi = opt.mat[a]; }
-    const int shift = (256 - (lo & 0xff)) & 0xff, qmax = hi;
-    int n_b = 0, te = -1, gmax = 0;
-    const int minsc = (xtra & KSW_XSUBO) ? xtra & 0xffff : 0x10000;
-    const int endsc = (xtra & KSW_XSTOP) ? xtra & 0xffff : 0x10000;
-    const bool la = lane < p;
-    const int l = la ? lane : 0;
-    const ScoreTab ST = score_tab(opt);
-    int H0[NSEG], H1[NSEG], E[NSEG], Hmax[NSEG], sn[NSEG];
-    uint32_t sp[NSEG];                                      // packed scores of the cell's query base against target bases 0..3
-    bool pad[NSEG];
-#pragma unroll
-    for (int j = 0; j < NSEG; ++j) {
-        const int pos = j + l * slen;
-        H0[j] = H1[j] = E[j] = Hmax[j] = 0;
-        pad[j] = !(j < slen && pos < qlen);
-        score_lane(ST, pad[j] ? 4 : sw_q(I, pos), sp[j], sn[j]);
-    }
-    bool stop = false;
-    PacCache pc; pc.w = -1; pc.v = 0;
-    for (int i = 0; i < tlen && !stop; ++i) {
-        const int tb = ref_base2_c(ix, pc, I.t0 + (i < I.trev ? I.trev - 1 - i : i));
-        int f = 0, mx = 0;
-        int hlast = 0;
-#pragma unroll
-        for (int j = 0; j < NSEG; ++j) if (j == slen - 1) hlast = H0[j];
-        int h = sw_shup1(la ? hlast : 0, lane);
-#pragma unroll
-        for (int j = 0; j < NSEG; ++j) {
-            if (j < slen) {
-                const int sc = (pad[j] ? 0 : score_at(sp[j], sn[j], tb)) + (u8 ? shift : 0);
-                int hh, ee = E[j], t;
-                if (u8) { hh = sat_u8(h + sc); hh = sat_u8(hh - shift); }
-                else hh = sat_i16(h + sc);
-                hh = hh > ee ? hh : ee;
-                hh = hh > f ? hh : f;
-                mx = mx > hh ? mx : hh;
-                H1[j] = hh;
-                if (u8) { ee = sat_u8(ee - e_del); t = sat_u8(hh - oe_del); }
-                else    { ee = subs_u16(ee, e_del); t = subs_u16(hh, oe_del); }
-                E[j] = ee > t ? ee : t;
-                if (u8) { f = sat_u8(f - e_ins); t = sat_u8(hh - oe_ins); }
-                else    { f = subs_u16(f, e_ins); t = subs_u16(hh, oe_ins); }
-                f = f > t ? f : t;
-                h = H0[j];
-            }
-        }
-        bool done = false;
-        for (int k = 0; k < 16 && !done; ++k) {            // lazy-F across segment boundaries
-            f = sw_shup1(la ? f : 0, lane);
-#pragma unroll
-            for (int j = 0; j < NSEG; ++j) {
-                if (j < slen && !done) {
-                    int hh = H1[j];
-                    hh = hh > f ? hh : f;
-                    H1[j] = hh;
-                    bool more;
-                    if (u8) { hh = sat_u8(hh - oe_ins); f = sat_u8(f - e_ins); more = sat_u8(f - hh) != 0; }
-                    else    { hh = subs_u16(hh, oe_ins); f = subs_u16(f, e_ins); more = f > hh; }
-                    if (__ballot(la && more) == 0ull) done = true;
-                }
-            }
-        }
-        int imax = la ? mx : 0;
-        for (int o = 8; o > 0; o >>= 1) { const int u = __shfl_xor(imax, o); imax = imax > u ? imax : u; }
-        imax = __shfl(imax, 0);
-        if (imax >= minsc) {
-            if (n_b == 0 || (int32_t)W.b[n_b - 1] + 1 != i) {
-                if (n_b >= W.cap_b) { err |= ERR_SCRATCH; return r; }
-                if (lane == 0) W.b[n_b] = (uint64_t)imax << 32 | (uint32_t)i;
-                ++n_b;
-            } else if ((int)(W.b[n_b - 1] >> 32) < imax) { if (lane == 0) W.b[n_b - 1] = (uint64_t)imax << 32 | (uint32_t)i; }
-            __syncthreads();
-        }
-        if (imax > gmax) {
-            gmax = imax; te = i;
-#pragma unroll
-            for (int j = 0; j < NSEG; ++j) Hmax[j] = H1[j];
-            if (u8) { if (gmax + shift >= 255 || gmax >= endsc) stop = true; }
-            else if (gmax >= endsc) stop = true;
-        }
-#pragma unroll
-        for (int j = 0; j < NSEG; ++j) { const int t = H0[j]; H0[j] = H1[j]; H1[j] = t; }
-    }
-    __syncthreads();
-    r.score = u8 ? (gmax + shift < 255 ? gmax : 255) : gmax;
-    r.te = te;
-    if (!u8 || r.score != 255) {
-        int best = -1, bq = 0x7fffffff;
-#pragma unroll
-        for (int j = 0; j < NSEG; ++j) {
-            if (la && j < slen) {
-                const int v = Hmax[j], pos = j + l * slen;
-                if (v > best || (v == best && pos < bq)) { best = v; bq = pos; }
-            }
-        }
-        for (int o = 8; o > 0; o >>= 1) {
-            const int ub = __shfl_xor(best, o), uq = __shfl_xor(bq, o);
-            if (ub > best || (ub == best && uq < bq)) { best = ub; bq = uq; }
-        }
-        r.qe = __shfl(bq, 0);
-        if (n_b > 0) {
-            int i = (r.score + qmax - 1) / qmax;
-            int low = te - i, high = te + i;
-            for (i = 0; i < n_b; ++i) {
-                int e = (int32_t)W.b[i];
-                if ((e < low || e > high) && (int)(W.b[i] >> 32) > r.score2) { r.score2 = (int)(W.b[i] >> 32); r.te2 = e; }
-            }
-        }
-    }
-    __syncthreads();
-    return r;
-}
-
-#define SW_REG_SEGS 10
-DEV KswR sw_core_wave_any(const DevIndex& ix, const MemOpt& opt, const SwIn& I, int size, int qlen, int tlen, int xtra, const SwLds& W, int lane, int& err)
-{
-    const int p = 8 * (3 - size);
-    if ((qlen + p - 1) / p <= SW_REG_SEGS) return sw_core_wave_reg<SW_REG_SEGS>(ix, opt, I, size, qlen, tlen, xtra, W, lane, err);
-    return sw_core_wave(ix, opt, I, size, qlen, tlen, xtra, W, lane, err);
-}
-
-DEV KswR sw_align2_wave(const DevIndex& ix, const MemOpt& opt, SwIn I, int qlen, int tlen, int xtra, const SwLds& W, int lane, int& err)
-{
-    const int size = (xtra & KSW_XBYTE) ? 1 : 2;
-    I.qrev = 0; I.trev = 0;
-    KswR r = sw_core_wave_any(ix, opt, I, size, qlen, tlen, xtra, W, lane, err);
-    if ((xtra & KSW_XSTART) == 0 || ((xtra & KSW_XSUBO) && r.score < (xtra & 0xffff))) return r;
-    I.qrev = r.qe + 1; I.trev = r.te + 1;
-    KswR rr = sw_core_wave_any(ix, opt, I, size, r.qe + 1, tlen, KSW_XSTOP | r.score, W, lane, err);
-    if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
-    return r;
-}
-
+// ------------------------------------------------------------------ the same kernel across the lanes of a wavefront
+// Mate rescue needs ksw_align2 over a ~600-base window for a few per cent of the pairs; the scalar form above, with its
+// arrays in global memory, takes ~0.4 s of dependent round trips per call.  In the wave form upstream's SSE2 lane k (16
+// bytes or 8 shorts per vector) is lane k of a 16-lane group, the segment loop and the lazy-F loop are the sequential
+// dimension exactly as upstream has them, the H/E/Hmax stripes and the query profile live in registers (NSEG segments)
+// and only the row-maxima list is in LDS.
+struct SwLds { uint64_t* b; int cap_b; };               // [4][cap_b] row-maxima lists, one per 16-lane group
 
 // Up to four alignments at once, one per 16-lane group of the wavefront (upstream's 16-byte vector is exactly one group; in
 // 16-bit mode the upper 8 lanes of a group idle).  A wave that owns several pairs in need of rescue would otherwise run their
 // alignments one after another while every other wave has finished.  All arguments are per lane but uniform within a group;
 // `on` says whether the group has an alignment at all; `size` (byte or 16-bit mode) is the same for the whole wave.
-// (kept out of line: inlined into the pairing kernel its register arrays end up spilled)
 template <int NSEG>
 static __device__ __attribute__((noinline)) KswR sw_core_wave4(const DevIndex& ix, const MemOpt& opt, const SwIn& I, bool on, int size, int qlen, int tlen, int xtra, const SwLds& W, int lane, int& err)
 {
@@ -549,14 +286,15 @@ static __device__ __attribute__((noinline)) KswR sw_core_wave4(const DevIndex& i
 }
 
 // ksw_align2 for up to four alignments (see sw_core_wave4); arguments per lane, uniform within a 16-lane group
+template <int NSEG>
 DEV KswR sw_align2_wave4(const DevIndex& ix, const MemOpt& opt, SwIn I, bool on, int size, int qlen, int tlen, int xtra, const SwLds& W, int lane, int& err)
 {
     I.qrev = 0; I.trev = 0;
-    KswR r = sw_core_wave4<SW_REG_SEGS>(ix, opt, I, on, size, qlen, tlen, xtra, W, lane, err);
+    KswR r = sw_core_wave4<NSEG>(ix, opt, I, on, size, qlen, tlen, xtra, W, lane, err);
     const bool again = on && !((xtra & KSW_XSTART) == 0 || ((xtra & KSW_XSUBO) && r.score < (xtra & 0xffff)));
     if (__ballot(again) == 0ull) return r;
     I.qrev = r.qe + 1; I.trev = r.te + 1;
-    KswR rr = sw_core_wave4<SW_REG_SEGS>(ix, opt, I, again, size, again ? r.qe + 1 : 0, tlen, KSW_XSTOP | r.score, W, lane, err);
+    KswR rr = sw_core_wave4<NSEG>(ix, opt, I, again, size, again ? r.qe + 1 : 0, tlen, KSW_XSTOP | r.score, W, lane, err);
     if (again && r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
     return r;
 }
