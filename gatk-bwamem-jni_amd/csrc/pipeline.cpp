@@ -20,6 +20,7 @@
 #include <condition_variable>
 #include <thread>
 #include <atomic>
+#include <functional>
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -68,6 +69,8 @@ struct Workspace {
     DevBuf out, out_len, out_off, post, err, cnt;
     DevBuf jobs, job_out, job_cig, job_cnt, zpool;   // single-end global-alignment jobs
     int job_cap = 0, job_cig_cap = 0; size_t zpool_cap = 0;
+    int out_cap_hint = 512;                           // bytes per read of the output staging slots (grown on overflow, kept across tiles)
+    DevBuf pe_dir, pe_is, pe_caps, pe_reg_off2, pe_regs2, pe_ints2, pe_vpool, pe_scratch, pe_states, pe_rescue[3];   // paired-end stages
     hipStream_t stream = nullptr;
     std::vector<Timed> timed;
 
@@ -96,7 +99,8 @@ struct Workspace {
     void release() {
         DevBuf* all[] = { &intv, &n_intv, &smem, &l_rep, &n_seeds, &seed_off, &intv_seed_off, &seeds, &seed_rid, &cseeds, &chains,
                           &chain_store, &n_chains, &bt_nodes, &srt, &regs, &n_regs, &out, &out_len, &out_off, &post, &err, &cnt,
-                          &jobs, &job_out, &job_cig, &job_cnt, &zpool };
+                          &jobs, &job_out, &job_cig, &job_cnt, &zpool, &pe_dir, &pe_is, &pe_caps, &pe_reg_off2, &pe_regs2, &pe_ints2, &pe_vpool, &pe_scratch, &pe_states,
+                          &pe_rescue[0], &pe_rescue[1], &pe_rescue[2] };
         for (DevBuf* b : all) b->release();
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     }
@@ -314,7 +318,6 @@ static void debug_dump(Workspace& ws, const TileView& tv, int T)
 // kept compact in HBM.  Then the batch-global insert-size statistics (mem_pestat) are reduced on the host
 // from per-pair (orientation, insert size) candidates -- the one cross-read dependency of the path
 //  -- and phase 2 (per tile) does mate rescue, pairing and record generation.
-struct PeTile { uint32_t r0 = 0; int T = 0, L = 0; DevBuf n_regs, regs, reg_off; int64_t n_regs_total = 0; };
 
 static void host_pestat(const MemOpt& opt, const std::vector<int8_t>& dir, const std::vector<int64_t>& is, MemPestat pes[4])
 {   // upstream mem_pestat after candidate collection (bwamem_pair.c); candidates arrive in pair order
@@ -349,193 +352,7 @@ static void host_pestat(const MemOpt& opt, const std::vector<int8_t>& dir, const
     for (int d = 0; d < 4; ++d) if (pes[d].failed == 0 && isize[d].size() < mx * 0.05) pes[d].failed = 1;
 }
 
-static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes0, bwamem_batch_s* b, int64_t read_id0)
-{
-    Workspace& ws = ix->ws;
-    const char* env_t = getenv("BWAMEM_HIP_TILE");
-    std::vector<PeTile*> tiles;
-    std::vector<int8_t> cand_dir; std::vector<int64_t> cand_is;
-    DevBuf d_dir, d_is, caps, reg_off2, regs2, ints2, vpool, pe_scratch, pe_states, rescue[3];
-    int pe_job_cap = 0, pe_rescue_cap = 0; size_t pe_zpool = 0;
-    bool ok = false;
-    int intv_cap_scale = 1, out_cap = 512;
-    auto cleanup = [&]() {
-        for (PeTile* t : tiles) { t->n_regs.release(); t->regs.release(); t->reg_off.release(); delete t; }
-        d_dir.release(); d_is.release(); caps.release(); reg_off2.release(); regs2.release(); ints2.release(); vpool.release(); pe_scratch.release(); pe_states.release(); rescue[0].release(); rescue[1].release(); rescue[2].release();
-    };
-#define PE_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "[bwamem_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); cleanup(); return false; } } while (0)
-#define PE_REQ(cond) do { if (!(cond)) { cleanup(); return false; } } while (0)
-    // ---------------- phase 1
-    uint32_t r0 = 0;
-    while (r0 < b->n_reads) {
-        int64_t budget = (int64_t)24 << 30;
-        int L0 = 1; uint32_t r1 = r0;
-        uint32_t max_T = env_t ? (uint32_t)atoi(env_t) : 262144u;
-        max_T = std::max(2u, max_T & ~1u);
-        while (r1 < b->n_reads && r1 - r0 < max_T) {
-            int len = (int)(b->h_off[r1 + 1] - b->h_off[r1] - 1);
-            int L1 = std::max(L0, len);
-            int icap = std::max(64, L1 + 8) * intv_cap_scale;
-            int64_t pr = (int64_t)icap * (sizeof(Intv) + 4) + 2 * (int64_t)(L1 + 2) * 16 + out_cap + post_bytes_per_read(L1, opt) + 64 * 300;
-            if (r1 > r0 + 1 && pr * (int64_t)(r1 - r0 + 1) > budget && ((r1 - r0) & 1) == 0) break;
-            L0 = L1; ++r1;
-        }
-        const int T = (int)(r1 - r0), L = L0;
-        int intv_cap = std::max(64, L + 8) * intv_cap_scale;
-        int attempts = 0;
-        for (;;) {
-            if (++attempts > 8) { fprintf(stderr, "[bwamem_hip] tile could not be sized after 8 attempts\n"); cleanup(); return false; }
-            PE_REQ(ws.ensure_reads(T, L, intv_cap, out_cap, post_bytes_per_read(L, opt)));
-            PE_REQ(ws.ensure_seeds(std::max<int64_t>(ws.seed_cap, (int64_t)T * 16)));
-            TileView tv = ws.view();
-            tv.n_reads = T; tv.max_len = L; tv.read_id0 = read_id0 + r0;
-            tv.seq = b->d_seq.as<uint8_t>(); tv.seq_off = b->d_off.as<int64_t>() + r0;
-            PE_OK(hipMemsetAsync(ws.err.p, 0, 64, ws.stream));
-            PE_OK(hipMemsetAsync(ws.cnt.p, 0, sizeof(DevCounters), ws.stream));
-            TIMED(ws, K_SEED, launch_seed(ws.stream, ix->d, opt, tv));
-            TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_seeds, tv.seed_off, T));
-            int64_t n_occ = 0; int32_t err = 0;
-            PE_OK(hipMemcpyAsync(&n_occ, tv.seed_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
-            PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
-            PE_OK(hipStreamSynchronize(ws.stream));
-            if (err & ERR_INTV_CAP) { intv_cap *= 2; intv_cap_scale *= 2; continue; }
-            if (n_occ > ws.seed_cap) {
-                PE_REQ(ws.ensure_seeds(n_occ + n_occ / 4));
-                TileView t2 = ws.view();
-                t2.n_reads = T; t2.max_len = L; t2.read_id0 = tv.read_id0; t2.seq = tv.seq; t2.seq_off = tv.seq_off;
-                tv = t2;
-            }
-            TIMED(ws, K_SA, launch_sa(ws.stream, ix->d, opt, tv, n_occ));
-            TIMED(ws, K_CHAIN, launch_chain(ws.stream, ix->d, opt, tv, ws.chain_store.as<Chain>()));
-        TIMED(ws, K_CHAIN, launch_rescore(ws.stream, ix->d, opt, tv));
-            TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
-            TIMED(ws, K_POST, launch_post1(ws.stream, ix->d, opt, tv));
-            PeTile* pt = new PeTile(); tiles.push_back(pt);
-            pt->r0 = r0; pt->T = T; pt->L = L;
-            PE_REQ(pt->n_regs.ensure((size_t)T * 4) && pt->reg_off.ensure(((size_t)T + 1) * 8));
-            TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_regs, pt->reg_off.as<int64_t>(), T));
-            DevCounters hc;
-            PE_OK(hipMemcpyAsync(&pt->n_regs_total, pt->reg_off.as<int64_t>() + T, 8, hipMemcpyDeviceToHost, ws.stream));
-            PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
-            PE_OK(hipMemcpyAsync(&hc, tv.cnt, sizeof hc, hipMemcpyDeviceToHost, ws.stream));
-            PE_OK(hipStreamSynchronize(ws.stream));
-            if (err) { fprintf(stderr, "[bwamem_hip] device error flags %d in the paired-end phase 1\n", err); cleanup(); return false; }
-            PE_REQ(pt->regs.ensure((size_t)(pt->n_regs_total + 1) * sizeof(AlnReg)));
-            PE_OK(hipMemcpyAsync(pt->n_regs.p, tv.n_regs, (size_t)T * 4, hipMemcpyDeviceToDevice, ws.stream));
-            TIMED(ws, K_OTHER, launch_pe_copy_regs(ws.stream, tv, tv.regs, tv.seed_off, pt->regs.as<AlnReg>(), pt->reg_off.as<int64_t>(), tv.n_regs));
-            if (!pes0) {
-                int np = T >> 1;
-                PE_REQ(d_dir.ensure((size_t)np + 8) && d_is.ensure((size_t)np * 8 + 8));
-                TIMED(ws, K_OTHER, launch_pestat_cand(ws.stream, ix->d, opt, tv, d_dir.as<int8_t>(), d_is.as<int64_t>()));
-                size_t at = cand_dir.size();
-                cand_dir.resize(at + np); cand_is.resize(at + np);
-                if (np) {
-                    PE_OK(hipMemcpyAsync(cand_dir.data() + at, d_dir.p, (size_t)np, hipMemcpyDeviceToHost, ws.stream));
-                    PE_OK(hipMemcpyAsync(cand_is.data() + at, d_is.p, (size_t)np * 8, hipMemcpyDeviceToHost, ws.stream));
-                }
-            }
-            PE_OK(hipStreamSynchronize(ws.stream));
-            {
-                std::lock_guard<std::mutex> lk(g_stats.mu);
-                g_stats.s.n_reads += T; g_stats.s.n_ext += hc.n_ext; g_stats.s.n_lf += hc.n_lf; g_stats.s.n_sa += hc.n_sa;
-                g_stats.s.n_dp_cells += hc.n_dp_cells; ++g_stats.s.n_tiles;
-            }
-            timed_collect(ws);
-            break;
-        }
-        r0 = r1;
-    }
-    // ---------------- insert-size statistics
-    MemPestat pes[4];
-    if (pes0) memcpy(pes, pes0, sizeof pes);
-    else host_pestat(opt, cand_dir, cand_is, pes);
-    // ---------------- phase 2
-    for (PeTile* pt : tiles) {
-        const int T = pt->T, L = pt->L;
-        int attempts = 0, cap_u = 256;
-        for (;;) {
-            if (++attempts > 6) { fprintf(stderr, "[bwamem_hip] paired-end tile could not be sized\n"); cleanup(); return false; }
-            PE_REQ(ws.ensure_reads(T, L, ws.intv_cap ? ws.intv_cap : 64, out_cap, post_bytes_per_read(L, opt)));
-            TileView tv = ws.view();
-            tv.n_reads = T; tv.max_len = L; tv.read_id0 = read_id0 + pt->r0;
-            tv.seq = b->d_seq.as<uint8_t>(); tv.seq_off = b->d_off.as<int64_t>() + pt->r0;
-            PE_OK(hipMemsetAsync(ws.err.p, 0, 64, ws.stream));
-            PE_OK(hipMemcpyAsync(tv.n_regs, pt->n_regs.p, (size_t)T * 4, hipMemcpyDeviceToDevice, ws.stream));
-            PE_REQ(caps.ensure((size_t)T * 4) && reg_off2.ensure(((size_t)T + 1) * 8));
-            TIMED(ws, K_OTHER, launch_pe_caps(ws.stream, opt, tv, caps.as<int32_t>()));
-            TIMED(ws, K_OTHER, launch_scan(ws.stream, caps.as<int32_t>(), reg_off2.as<int64_t>(), T));
-            int64_t tot = 0;
-            PE_OK(hipMemcpyAsync(&tot, reg_off2.as<int64_t>() + T, 8, hipMemcpyDeviceToHost, ws.stream));
-            PE_OK(hipStreamSynchronize(ws.stream));
-            int span = 0;
-            for (int d = 0; d < 4; ++d) if (!pes[d].failed) span = std::max(span, pes[d].high - pes[d].low);
-            const int cap_h = L + 32, cap_b = (span + 2 * L) / 2 + 16;
-            const int64_t per_pair = (((int64_t)16 * cap_h + (int64_t)8 * cap_b + (int64_t)2 * opt.max_matesw * sizeof(AlnReg) + (int64_t)16 * cap_u) + 63) & ~(int64_t)63;
-            PE_REQ(regs2.ensure((size_t)(tot + 1) * sizeof(AlnReg)) && ints2.ensure((size_t)(tot + 1) * 8) && vpool.ensure((size_t)(tot + 2) * 16)
-                   && pe_scratch.ensure((size_t)((T >> 1) + 1) * (size_t)per_pair));
-            TIMED(ws, K_OTHER, launch_pe_copy_regs(ws.stream, tv, pt->regs.as<AlnReg>(), pt->reg_off.as<int64_t>(), regs2.as<AlnReg>(), reg_off2.as<int64_t>(), tv.n_regs));
-            // pairing decisions and the list of regions whose CIGAR needs DP; the DP jobs; the records
-            PE_REQ(ws.ensure_jobs(std::max(pe_job_cap, std::max(1024, T / 2)), 4 * L + 16,
-                                  std::max(pe_zpool, (size_t)std::max(pe_job_cap, std::max(1024, T / 2)) * (size_t)(2 * L + 64) * 20 + ((size_t)64 << 20))));
-            PE_REQ(pe_states.ensure(pe_state_bytes(T)));
-            {   // the job buffers may have moved
-                TileView t2 = ws.view();
-                t2.n_reads = T; t2.max_len = L; t2.read_id0 = tv.read_id0; t2.seq = tv.seq; t2.seq_off = tv.seq_off;
-                tv = t2;
-            }
-            PE_OK(hipMemsetAsync(ws.job_cnt.p, 0, 64, ws.stream));
-            {   // rescue alignments: a few per cent of the pairs ask for one, pairs in repeats for many
-                const int rc = std::max(pe_rescue_cap, std::max(4096, T / 8));
-                PE_REQ(rescue[0].ensure(pe_rescue_bytes(0, rc)) && rescue[1].ensure(pe_rescue_bytes(1, rc)) && rescue[2].ensure((size_t)(T / 2 + 1) * 8 + 64));
-                pe_rescue_cap = rc;
-            }
-            TIMED(ws, K_FINAL, launch_pe_pair(ws.stream, ix->d, opt, tv, regs2.as<AlnReg>(), reg_off2.as<int64_t>(), tv.n_regs, ints2.as<int32_t>(), vpool.p,
-                                              pe_scratch.as<uint8_t>(), per_pair, cap_h, cap_b, cap_u, pes, pe_states.p,
-                                              rescue[0].p, rescue[1].p, rescue[2].as<int32_t>() + 16, rescue[2].as<int32_t>() + 16 + (T / 2 + 1), rescue[2].as<int32_t>(), pe_rescue_cap));
-            int32_t n_jobs = 0, err = 0;
-            PE_OK(hipMemcpyAsync(&n_jobs, tv.job_cnt, 4, hipMemcpyDeviceToHost, ws.stream));
-            PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
-            PE_OK(hipStreamSynchronize(ws.stream));
-            int32_t n_rescue = 0;
-            PE_OK(hipMemcpy(&n_rescue, rescue[2].p, 4, hipMemcpyDeviceToHost));
-            if (n_rescue > pe_rescue_cap) { pe_rescue_cap = n_rescue + n_rescue / 4; continue; }
-            if ((err & ERR_JOB_CAP) || n_jobs > ws.job_cap) { pe_job_cap = std::max(n_jobs + n_jobs / 4, ws.job_cap * 2); continue; }
-            if (err & ERR_SCRATCH) { cap_u *= 8; if (attempts < 4) continue; }
-            if (err) { fprintf(stderr, "[bwamem_hip] device error flags %d in the paired-end pairing stage\n", err); cleanup(); return false; }
-            {
-                TileView tvj = tv;                              // the job kernels address a region as regs[seed_off[read] + index]
-                tvj.regs = regs2.as<AlnReg>(); tvj.seed_off = reg_off2.as<int64_t>();
-                TIMED(ws, K_FINAL, launch_gcigar(ws.stream, ix->d, opt, tvj, n_jobs, ws.jobs.p, ws.job_out.p, ws.job_cig.as<uint32_t>(), ws.job_cig_cap,
-                                                 ws.zpool.as<uint8_t>(), (unsigned long long)ws.zpool_cap, (unsigned long long*)(ws.job_cnt.as<int32_t>() + 2)));
-            }
-            TIMED(ws, K_FINAL, launch_pe_out(ws.stream, ix->d, opt, tv, regs2.as<AlnReg>(), reg_off2.as<int64_t>(), tv.n_regs, ints2.as<int32_t>(), pes, pe_states.p,
-                                             ws.job_out.p, ws.job_cig.as<uint32_t>(), ws.job_cig_cap));
-            TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.out_len, tv.out_off, T));
-            int64_t out_total = 0;
-            PE_OK(hipMemcpyAsync(&out_total, tv.out_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
-            PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
-            PE_OK(hipStreamSynchronize(ws.stream));
-            if (err & ERR_OUT_CAP) { out_cap *= 4; continue; }
-            if (err & ERR_ZPOOL) { pe_zpool = std::max(pe_zpool * 4, ws.zpool_cap * 4); continue; }
-            if (err) { fprintf(stderr, "[bwamem_hip] device error flags %d in the paired-end phase 2\n", err); cleanup(); return false; }
-            TileOut to; to.bytes = (size_t)out_total;
-            if (out_total > 0) {
-                PE_OK(hipMalloc((void**)&to.d, (size_t)out_total));
-                TIMED(ws, K_PACK, launch_pack(ws.stream, tv, to.d));
-                PE_OK(hipStreamSynchronize(ws.stream));
-            }
-            b->tiles.push_back(to);
-            b->result_bytes += to.bytes;
-            timed_collect(ws);
-            break;
-        }
-    }
-    ok = true;
-    cleanup();
-    return ok;
-#undef PE_OK
-#undef PE_REQ
-}
+static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes0, bwamem_batch_s* b, int64_t read_id0);
 
 struct TileSpec { uint32_t r0, r1; int L; };
 
@@ -703,25 +520,12 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
     }
 }
 
-// Tiles are independent, and every kernel of a tile ends in a tail of a few long-running reads; several tiles are
-// therefore kept in flight on separate HIP streams (one host thread + workspace each) so that one tile's tail
-// overlaps the next tile's bulk.
-static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, bwamem_batch_s* b, int64_t read_id0)
+// Runs fn for every tile on worker threads (one stream + workspace each, BWAMEM_HIP_STREAMS of them), with the seeding
+// stage one chunk of tiles ahead on its own stream: fn finds the interval lists of its tile in the store it is handed
+// (at offset r0 - chunk_r0).
+typedef std::function<bool(Workspace&, size_t, const SeedStore&, uint32_t)> TileFn;
+static bool run_tiles_seeded(bwaidx_s* ix, const MemOpt& opt, bwamem_batch_s* b, const std::vector<TileSpec>& specs, const TileFn& fn)
 {
-    HIP_OK(hipSetDevice(ix->device));
-    Workspace& ws = ix->ws;
-    if (!ws.stream) HIP_OK(hipStreamCreate(&ws.stream));
-    for (TileOut& t : b->tiles) if (t.d) (void)hipFree(t.d);
-    b->tiles.clear(); b->result_bytes = 0;
-    if (b->n_reads == 0) return true;
-    HIP_OK(hipMemcpyAsync(b->d_seq.p, b->d_raw.p, b->n_bytes, hipMemcpyDeviceToDevice, ws.stream));
-    TIMED(ws, K_ENCODE, launch_encode(ws.stream, b->d_seq.as<uint8_t>(), (int64_t)b->n_bytes));
-    if (opt.flag & MEM_F_PE) return align_batch_pe(ix, opt, pes, b, read_id0);
-    HIP_OK(hipStreamSynchronize(ws.stream));
-    timed_collect(ws);
-    const std::vector<TileSpec> specs = plan_tiles(b, opt, false, false);
-    for (const TileSpec& t : specs) if (t.L >= (1 << 17) - 1) { fprintf(stderr, "[bwamem_hip] reads of 131071 bases or more are not supported\n"); return false; }
-    b->tiles.assign(specs.size(), TileOut());
     const char* env_s = getenv("BWAMEM_HIP_STREAMS");
     int n_workers = std::max(1, std::min<int>((int)specs.size(), env_s ? atoi(env_s) : 4));
     while ((int)ix->extra_ws.size() < n_workers - 1) ix->extra_ws.push_back(new Workspace());
@@ -776,14 +580,13 @@ static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, b
         Workspace& w = k == 0 ? ix->ws : *ix->extra_ws[k - 1];
         if (hipSetDevice(ix->device) != hipSuccess) { failed = true; cv.notify_all(); return; }
         if (!w.stream && hipStreamCreate(&w.stream) != hipSuccess) { failed = true; cv.notify_all(); return; }
-        int out_cap = 512;
         while (!failed) {
             size_t i = next++;
             if (i >= specs.size()) break;
             const size_t c = chunk_of[i];
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return failed || chunks[c].state != 0; }); }
             if (failed) break;
-            if (!run_tile_se(ix, w, opt, b, read_id0, specs[i], b->tiles[i], ix->seed_store[c & 1], chunks[c].r0, out_cap)) failed = true;
+            if (!fn(w, i, ix->seed_store[c & 1], chunks[c].r0)) failed = true;
             { std::lock_guard<std::mutex> lk(mu); --chunks[c].tiles_left; }
             cv.notify_all();
         }
@@ -794,7 +597,236 @@ static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, b
     for (int k = 1; k < n_workers; ++k) th.emplace_back(worker, k);
     worker(0);
     for (std::thread& t : th) t.join();
-    if (failed) return false;
+    return !failed;
+}
+
+// ---------------------------------------------------------------------------------------- paired-end call
+// Phase 1 (per tile, tiles in flight like single-end, seeding in chunks): seeds .. regions of every read, kept per tile,
+// and the per-pair insert-size candidates.  Then the batch-global statistics on the host (mem_pestat), unless the caller
+// supplied them.  Phase 2 (per tile, tiles in flight): mate rescue, pairing, DP jobs, records.
+struct PeTile { uint32_t r0 = 0; int T = 0, L = 0; DevBuf n_regs, regs, reg_off; int64_t n_regs_total = 0; std::vector<int8_t> cand_dir; std::vector<int64_t> cand_is; };
+
+#define PE_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "[bwamem_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return false; } } while (0)
+#define PE_REQ(cond) do { if (!(cond)) return false; } while (0)
+
+static bool pe_phase1_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_batch_s* b, int64_t read_id0, const TileSpec& spec, PeTile* pt,
+                           const SeedStore& seeds_of_chunk, uint32_t chunk_r0, bool want_cand)
+{
+    const uint32_t r0 = spec.r0;
+    const int T = (int)(spec.r1 - spec.r0), L = spec.L;
+    PE_REQ(ws.ensure_reads(T, L, seeds_of_chunk.cap, ws.out_cap_hint, post_bytes_per_read(L, opt, false), false));
+    PE_REQ(ws.ensure_seeds(std::max<int64_t>(ws.seed_cap, (int64_t)T * 16)));
+    auto make_view = [&]() {
+        TileView v = ws.view();
+        v.n_reads = T; v.max_len = L; v.read_id0 = read_id0 + r0;
+        v.seq = b->d_seq.as<uint8_t>(); v.seq_off = b->d_off.as<int64_t>() + r0;
+        const size_t at = (size_t)(r0 - chunk_r0);
+        v.intv_cap = seeds_of_chunk.cap;
+        v.intv = seeds_of_chunk.intv.as<Intv>() + at * seeds_of_chunk.cap;
+        v.intv_seed_off = seeds_of_chunk.intv_seed_off.as<int32_t>() + at * seeds_of_chunk.cap;
+        v.n_intv = seeds_of_chunk.n_intv.as<int32_t>() + at;
+        v.n_seeds = seeds_of_chunk.n_seeds.as<int32_t>() + at;
+        v.l_rep = seeds_of_chunk.l_rep.as<int32_t>() + at;
+        v.smem_scratch = nullptr; v.smem_groups = 0;
+        return v;
+    };
+    TileView tv = make_view();
+    PE_OK(hipMemsetAsync(ws.err.p, 0, 64, ws.stream));
+    PE_OK(hipMemsetAsync(ws.cnt.p, 0, sizeof(DevCounters), ws.stream));
+    TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_seeds, tv.seed_off, T));
+    int64_t n_occ = 0; int32_t err = 0;
+    PE_OK(hipMemcpyAsync(&n_occ, tv.seed_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
+    PE_OK(hipStreamSynchronize(ws.stream));
+    if (n_occ > ws.seed_cap) { PE_REQ(ws.ensure_seeds(n_occ + n_occ / 4)); tv = make_view(); }
+    TIMED(ws, K_SA, launch_sa(ws.stream, ix->d, opt, tv, n_occ));
+    TIMED(ws, K_CHAIN, launch_chain(ws.stream, ix->d, opt, tv, ws.chain_store.as<Chain>()));
+    TIMED(ws, K_CHAIN, launch_rescore(ws.stream, ix->d, opt, tv));
+    TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
+    TIMED(ws, K_POST, launch_post1(ws.stream, ix->d, opt, tv));
+    pt->r0 = r0; pt->T = T; pt->L = L;
+    PE_REQ(pt->n_regs.ensure((size_t)T * 4) && pt->reg_off.ensure(((size_t)T + 1) * 8));
+    TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_regs, pt->reg_off.as<int64_t>(), T));
+    DevCounters hc;
+    PE_OK(hipMemcpyAsync(&pt->n_regs_total, pt->reg_off.as<int64_t>() + T, 8, hipMemcpyDeviceToHost, ws.stream));
+    PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
+    PE_OK(hipMemcpyAsync(&hc, tv.cnt, sizeof hc, hipMemcpyDeviceToHost, ws.stream));
+    PE_OK(hipStreamSynchronize(ws.stream));
+    if (err) { fprintf(stderr, "[bwamem_hip] device error flags %d in the paired-end phase 1\n", err); return false; }
+    PE_REQ(pt->regs.ensure((size_t)(pt->n_regs_total + 1) * sizeof(AlnReg)));
+    PE_OK(hipMemcpyAsync(pt->n_regs.p, tv.n_regs, (size_t)T * 4, hipMemcpyDeviceToDevice, ws.stream));
+    TIMED(ws, K_OTHER, launch_pe_copy_regs(ws.stream, tv, tv.regs, tv.seed_off, pt->regs.as<AlnReg>(), pt->reg_off.as<int64_t>(), tv.n_regs));
+    if (want_cand) {
+        const int np = T >> 1;
+        PE_REQ(ws.pe_dir.ensure((size_t)np + 8) && ws.pe_is.ensure((size_t)np * 8 + 8));
+        TIMED(ws, K_OTHER, launch_pestat_cand(ws.stream, ix->d, opt, tv, ws.pe_dir.as<int8_t>(), ws.pe_is.as<int64_t>()));
+        pt->cand_dir.resize(np); pt->cand_is.resize(np);
+        if (np) {
+            PE_OK(hipMemcpyAsync(pt->cand_dir.data(), ws.pe_dir.p, (size_t)np, hipMemcpyDeviceToHost, ws.stream));
+            PE_OK(hipMemcpyAsync(pt->cand_is.data(), ws.pe_is.p, (size_t)np * 8, hipMemcpyDeviceToHost, ws.stream));
+        }
+    }
+    PE_OK(hipStreamSynchronize(ws.stream));
+    {
+        std::lock_guard<std::mutex> lk(g_stats.mu);
+        g_stats.s.n_reads += T; g_stats.s.n_lf += hc.n_lf; g_stats.s.n_sa += hc.n_sa; g_stats.s.n_dp_cells += hc.n_dp_cells; ++g_stats.s.n_tiles;
+    }
+    timed_collect(ws);
+    return true;
+}
+
+static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_batch_s* b, int64_t read_id0, PeTile* pt, const MemPestat* pes, TileOut& to)
+{
+    const int T = pt->T, L = pt->L;
+    int attempts = 0, cap_u = 256, pe_job_cap = 0, pe_rescue_cap = 0;
+    size_t pe_zpool = 0;
+    for (;;) {
+        if (++attempts > 8) { fprintf(stderr, "[bwamem_hip] paired-end tile could not be sized\n"); return false; }
+        PE_REQ(ws.ensure_reads(T, L, 0, ws.out_cap_hint, post_bytes_per_read(L, opt, false), false));
+        TileView tv = ws.view();
+        tv.n_reads = T; tv.max_len = L; tv.read_id0 = read_id0 + pt->r0;
+        tv.seq = b->d_seq.as<uint8_t>(); tv.seq_off = b->d_off.as<int64_t>() + pt->r0;
+        PE_OK(hipMemsetAsync(ws.err.p, 0, 64, ws.stream));
+        PE_OK(hipMemcpyAsync(tv.n_regs, pt->n_regs.p, (size_t)T * 4, hipMemcpyDeviceToDevice, ws.stream));
+        PE_REQ(ws.pe_caps.ensure((size_t)T * 4) && ws.pe_reg_off2.ensure(((size_t)T + 1) * 8));
+        TIMED(ws, K_OTHER, launch_pe_caps(ws.stream, opt, tv, ws.pe_caps.as<int32_t>()));
+        TIMED(ws, K_OTHER, launch_scan(ws.stream, ws.pe_caps.as<int32_t>(), ws.pe_reg_off2.as<int64_t>(), T));
+        int64_t tot = 0;
+        PE_OK(hipMemcpyAsync(&tot, ws.pe_reg_off2.as<int64_t>() + T, 8, hipMemcpyDeviceToHost, ws.stream));
+        PE_OK(hipStreamSynchronize(ws.stream));
+        int span = 0;
+        for (int d = 0; d < 4; ++d) if (!pes[d].failed) span = std::max(span, pes[d].high - pes[d].low);
+        const int cap_h = L + 32, cap_b = (span + 2 * L) / 2 + 16;
+        const int64_t per_pair = (((int64_t)16 * cap_h + (int64_t)8 * cap_b + (int64_t)2 * opt.max_matesw * sizeof(AlnReg) + (int64_t)16 * cap_u) + 63) & ~(int64_t)63;
+        PE_REQ(ws.pe_regs2.ensure((size_t)(tot + 1) * sizeof(AlnReg)) && ws.pe_ints2.ensure((size_t)(tot + 1) * 8) && ws.pe_vpool.ensure((size_t)(tot + 2) * 16)
+               && ws.pe_scratch.ensure((size_t)((T >> 1) + 1) * (size_t)per_pair));
+        AlnReg* regs2 = ws.pe_regs2.as<AlnReg>(); int64_t* reg_off2 = ws.pe_reg_off2.as<int64_t>();
+        TIMED(ws, K_OTHER, launch_pe_copy_regs(ws.stream, tv, pt->regs.as<AlnReg>(), pt->reg_off.as<int64_t>(), regs2, reg_off2, tv.n_regs));
+        // pairing decisions and the list of regions whose CIGAR needs DP; the DP jobs; the records
+        const int jc = std::max(pe_job_cap, std::max(1024, T / 2));
+        PE_REQ(ws.ensure_jobs(jc, 4 * L + 16, std::max(pe_zpool, (size_t)jc * (size_t)(2 * L + 64) * 20 + ((size_t)64 << 20))));
+        PE_REQ(ws.pe_states.ensure(pe_state_bytes(T)));
+        {   // the job buffers may have moved
+            TileView t2 = ws.view();
+            t2.n_reads = T; t2.max_len = L; t2.read_id0 = tv.read_id0; t2.seq = tv.seq; t2.seq_off = tv.seq_off;
+            tv = t2;
+        }
+        PE_OK(hipMemsetAsync(ws.job_cnt.p, 0, 64, ws.stream));
+        {   // rescue alignments: a few per cent of the pairs ask for one, pairs in repeats for many
+            const int rc = std::max(pe_rescue_cap, std::max(4096, T / 8));
+            PE_REQ(ws.pe_rescue[0].ensure(pe_rescue_bytes(0, rc)) && ws.pe_rescue[1].ensure(pe_rescue_bytes(1, rc)) && ws.pe_rescue[2].ensure((size_t)(T / 2 + 1) * 8 + 64));
+            pe_rescue_cap = rc;
+        }
+        TIMED(ws, K_FINAL, launch_pe_pair(ws.stream, ix->d, opt, tv, regs2, reg_off2, tv.n_regs, ws.pe_ints2.as<int32_t>(), ws.pe_vpool.p,
+                                          ws.pe_scratch.as<uint8_t>(), per_pair, cap_h, cap_b, cap_u, pes, ws.pe_states.p,
+                                          ws.pe_rescue[0].p, ws.pe_rescue[1].p, ws.pe_rescue[2].as<int32_t>() + 16, ws.pe_rescue[2].as<int32_t>() + 16 + (T / 2 + 1),
+                                          ws.pe_rescue[2].as<int32_t>(), pe_rescue_cap));
+        int32_t n_jobs = 0, err = 0, n_rescue = 0;
+        PE_OK(hipMemcpyAsync(&n_jobs, tv.job_cnt, 4, hipMemcpyDeviceToHost, ws.stream));
+        PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
+        PE_OK(hipMemcpyAsync(&n_rescue, ws.pe_rescue[2].p, 4, hipMemcpyDeviceToHost, ws.stream));
+        PE_OK(hipStreamSynchronize(ws.stream));
+        if (n_rescue > pe_rescue_cap) { pe_rescue_cap = n_rescue + n_rescue / 4; continue; }
+        if ((err & ERR_JOB_CAP) || n_jobs > ws.job_cap) { pe_job_cap = std::max(n_jobs + n_jobs / 4, ws.job_cap * 2); continue; }
+        if (err & ERR_SCRATCH) { cap_u *= 8; if (attempts < 4) continue; }
+        if (err) { fprintf(stderr, "[bwamem_hip] device error flags %d in the paired-end pairing stage\n", err); return false; }
+        {
+            TileView tvj = tv;                              // the job kernels address a region as regs[seed_off[read] + index]
+            tvj.regs = regs2; tvj.seed_off = reg_off2;
+            TIMED(ws, K_FINAL, launch_gcigar(ws.stream, ix->d, opt, tvj, n_jobs, ws.jobs.p, ws.job_out.p, ws.job_cig.as<uint32_t>(), ws.job_cig_cap,
+                                             ws.zpool.as<uint8_t>(), (unsigned long long)ws.zpool_cap, (unsigned long long*)(ws.job_cnt.as<int32_t>() + 2)));
+        }
+        TIMED(ws, K_FINAL, launch_pe_out(ws.stream, ix->d, opt, tv, regs2, reg_off2, tv.n_regs, ws.pe_ints2.as<int32_t>(), pes, ws.pe_states.p,
+                                         ws.job_out.p, ws.job_cig.as<uint32_t>(), ws.job_cig_cap));
+        TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.out_len, tv.out_off, T));
+        int64_t out_total = 0;
+        PE_OK(hipMemcpyAsync(&out_total, tv.out_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
+        PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
+        PE_OK(hipStreamSynchronize(ws.stream));
+        if (err & ERR_OUT_CAP) { ws.out_cap_hint *= 4; continue; }
+        if (err & ERR_ZPOOL) { pe_zpool = std::max(pe_zpool * 4, ws.zpool_cap * 4); continue; }
+        if (err) { fprintf(stderr, "[bwamem_hip] device error flags %d in the paired-end phase 2\n", err); return false; }
+        to.bytes = (size_t)out_total; to.d = nullptr;
+        if (out_total > 0) {
+            PE_OK(hipMalloc((void**)&to.d, (size_t)out_total));
+            TIMED(ws, K_PACK, launch_pack(ws.stream, tv, to.d));
+            PE_OK(hipStreamSynchronize(ws.stream));
+        }
+        timed_collect(ws);
+        return true;
+    }
+}
+#undef PE_OK
+#undef PE_REQ
+
+static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes0, bwamem_batch_s* b, int64_t read_id0)
+{
+    const std::vector<TileSpec> specs = plan_tiles(b, opt, true, false);
+    for (const TileSpec& t : specs) if (t.L >= (1 << 17) - 1) { fprintf(stderr, "[bwamem_hip] reads of 131071 bases or more are not supported\n"); return false; }
+    std::vector<PeTile> tiles(specs.size());
+    auto cleanup = [&]() { for (PeTile& t : tiles) { t.n_regs.release(); t.regs.release(); t.reg_off.release(); } };
+    b->tiles.assign(specs.size(), TileOut());
+    // ---------------- phase 1
+    if (!run_tiles_seeded(ix, opt, b, specs, [&](Workspace& w, size_t i, const SeedStore& store, uint32_t chunk_r0) {
+            return pe_phase1_tile(ix, w, opt, b, read_id0, specs[i], &tiles[i], store, chunk_r0, pes0 == nullptr);
+        })) { cleanup(); return false; }
+    // ---------------- insert-size statistics (candidates in pair order)
+    MemPestat pes[4];
+    if (pes0) memcpy(pes, pes0, sizeof pes);
+    else {
+        std::vector<int8_t> cand_dir; std::vector<int64_t> cand_is;
+        for (PeTile& t : tiles) { cand_dir.insert(cand_dir.end(), t.cand_dir.begin(), t.cand_dir.end()); cand_is.insert(cand_is.end(), t.cand_is.begin(), t.cand_is.end()); }
+        host_pestat(opt, cand_dir, cand_is, pes);
+    }
+    // ---------------- phase 2: tiles in flight on the same worker streams
+    {
+        const char* env_s = getenv("BWAMEM_HIP_STREAMS");
+        const int n_workers = std::max(1, std::min<int>((int)specs.size(), env_s ? atoi(env_s) : 4));
+        while ((int)ix->extra_ws.size() < n_workers - 1) ix->extra_ws.push_back(new Workspace());
+        std::atomic<size_t> next(0);
+        std::atomic<bool> failed(false);
+        auto worker = [&](int k) {
+            Workspace& w = k == 0 ? ix->ws : *ix->extra_ws[k - 1];
+            if (hipSetDevice(ix->device) != hipSuccess) { failed = true; return; }
+            if (!w.stream && hipStreamCreate(&w.stream) != hipSuccess) { failed = true; return; }
+            while (!failed) {
+                const size_t i = next++;
+                if (i >= specs.size()) break;
+                if (!pe_phase2_tile(ix, w, opt, b, read_id0, &tiles[i], pes, b->tiles[i])) failed = true;
+            }
+        };
+        std::vector<std::thread> th;
+        for (int k = 1; k < n_workers; ++k) th.emplace_back(worker, k);
+        worker(0);
+        for (std::thread& t : th) t.join();
+        if (failed) { cleanup(); return false; }
+    }
+    for (const TileOut& t : b->tiles) b->result_bytes += t.bytes;
+    cleanup();
+    return true;
+}
+
+// Tiles are independent, and every kernel of a tile ends in a tail of a few long-running reads; several tiles are
+// therefore kept in flight on separate HIP streams (one host thread + workspace each) so that one tile's tail
+// overlaps the next tile's bulk.
+static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, bwamem_batch_s* b, int64_t read_id0)
+{
+    HIP_OK(hipSetDevice(ix->device));
+    Workspace& ws = ix->ws;
+    if (!ws.stream) HIP_OK(hipStreamCreate(&ws.stream));
+    for (TileOut& t : b->tiles) if (t.d) (void)hipFree(t.d);
+    b->tiles.clear(); b->result_bytes = 0;
+    if (b->n_reads == 0) return true;
+    HIP_OK(hipMemcpyAsync(b->d_seq.p, b->d_raw.p, b->n_bytes, hipMemcpyDeviceToDevice, ws.stream));
+    TIMED(ws, K_ENCODE, launch_encode(ws.stream, b->d_seq.as<uint8_t>(), (int64_t)b->n_bytes));
+    HIP_OK(hipStreamSynchronize(ws.stream));
+    timed_collect(ws);
+    if (opt.flag & MEM_F_PE) return align_batch_pe(ix, opt, pes, b, read_id0);
+    const std::vector<TileSpec> specs = plan_tiles(b, opt, false, false);
+    for (const TileSpec& t : specs) if (t.L >= (1 << 17) - 1) { fprintf(stderr, "[bwamem_hip] reads of 131071 bases or more are not supported\n"); return false; }
+    b->tiles.assign(specs.size(), TileOut());
+    if (!run_tiles_seeded(ix, opt, b, specs, [&](Workspace& w, size_t i, const SeedStore& store, uint32_t chunk_r0) {
+            return run_tile_se(ix, w, opt, b, read_id0, specs[i], b->tiles[i], store, chunk_r0, w.out_cap_hint);
+        })) return false;
     for (const TileOut& t : b->tiles) b->result_bytes += t.bytes;
     return true;
 }
