@@ -100,6 +100,10 @@ struct AlnReg {
     uint64_t hash;
 };
 
+// one ksw_align2 of a read (or a stretch of it) against a reference window, run by the wave SW kernel (k_pe.hip)
+struct SwJob { int64_t rb; int32_t read, tag, l_ms, is_rev, tlen, xtra, q_off, pad_; };
+struct KswR { int score, te, qe, score2, te2, tb, qb; };
+
 // per-kernel algorithmic counters; accumulated with one atomic per wave
 struct DevCounters {
     unsigned long long n_ext, n_lf, n_sa, n_dp_cells, n_ref_bases, n_reads;

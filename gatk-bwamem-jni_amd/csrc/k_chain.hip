@@ -298,46 +298,91 @@ __global__ void k_chain(DevIndex ix, MemOpt opt, TileView tv, Chain* chain_store
 }
 
 // mem_flt_chained_seeds + mem_seed_sw (row a10): for reads long enough that 5.5 ln L <= 0.05 L, every short seed is
-// re-scored by a local SW in a +-50 bp window and dropped when it scores below the HSP threshold.  One lane per read;
-// launched only for tiles that contain such reads.
+// re-scored by a local SW in a +-50 bp window and dropped when it scores below the HSP threshold.  The alignments are
+// independent of one another, so a lane per read lists them (k_rescore_plan), the wave SW kernel of mate rescue runs
+// them four per wavefront (k_pe.hip), and a lane per read applies the scores (k_rescore_apply).  Launched only for
+// tiles that contain such reads.
 #define MEM_SHORT_EXT 50
 #define MEM_SHORT_LEN 200
 
-DEV int seed_sw(const DevIndex& ix, const MemOpt& opt, int l_query, const uint8_t* query, const Seed& s, SwScratch& W, int& err)
+// window of mem_seed_sw; false: the seed keeps its exact-match score (upstream returns -1)
+DEV bool seed_sw_window(const DevIndex& ix, int l_query, const Seed& s, int& qb, int& qe, int64_t& rb, int64_t& re)
 {
     const int64_t l_pac = ix.l_pac;
-    if (s.len >= MEM_SHORT_LEN) return -1;
-    int qb = s.qbeg, qe = s.qbeg + s.len, rid;
-    int64_t rb = s.rbeg, re = s.rbeg + s.len, mid = (rb + re) >> 1;
+    if (s.len >= MEM_SHORT_LEN) return false;
+    int rid;
+    qb = s.qbeg; qe = s.qbeg + s.len;
+    rb = s.rbeg; re = s.rbeg + s.len;
+    const int64_t mid = (rb + re) >> 1;
     qb -= MEM_SHORT_EXT; qb = qb > 0 ? qb : 0;
     qe += MEM_SHORT_EXT; qe = qe < l_query ? qe : l_query;
     rb -= MEM_SHORT_EXT; rb = rb > 0 ? rb : 0;
     re += MEM_SHORT_EXT; re = re < l_pac << 1 ? re : l_pac << 1;
     if (rb < l_pac && l_pac < re) { if (mid < l_pac) re = l_pac; else rb = l_pac; }
-    if (qe - qb >= MEM_SHORT_LEN || re - rb >= MEM_SHORT_LEN) return -1;
+    if (qe - qb >= MEM_SHORT_LEN || re - rb >= MEM_SHORT_LEN) return false;
     bns_clamp(ix, rb, mid, re, rid);
-    SwIn I; I.ms = query + qb; I.l_ms = qe - qb; I.is_rev = 0; I.qrev = 0; I.t0 = rb; I.trev = 0;
-    // ksw_align2(..., KSW_XSTART): only the score of the first pass is used by the caller
-    KswR x = sw_core(ix, opt, I, 2, qe - qb, (int)(re - rb), KSW_XSTART, W, err);
-    return x.score;
+    return true;
 }
 
-__global__ void k_rescore(DevIndex ix, MemOpt opt, TileView tv)
+// does this read go through mem_flt_chained_seeds, and with which threshold?
+DEV bool rescore_read(const DevIndex& ix, const MemOpt& opt, const TileView& tv, int r, int& l_query, int& min_HSP_score)
 {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= tv.n_reads) return;
-    const int l_query = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
-    const int n_chn = tv.n_chains[r];
-    if (n_chn == 0) return;
-    if (l_query >= ix.log_tab_n) { atomicOr(tv.err, ERR_SCRATCH); return; }
+    l_query = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
+    if (tv.n_chains[r] == 0) return false;
+    if (l_query >= ix.log_tab_n) { atomicOr(tv.err, ERR_SCRATCH); return false; }
     const double min_l = opt.min_chain_weight ? 1.1f * opt.min_chain_weight : 5.5f * ix.log_tab[l_query];
-    const int min_HSP_score = (int)(opt.a * min_l + .499);
-    if (min_l > 0.05f * l_query) return;             // short reads: nothing to do
+    min_HSP_score = (int)(opt.a * min_l + .499);
+    return !(min_l > 0.05f * l_query);               // short reads: nothing to do
+}
+
+__global__ void k_rescore_plan(DevIndex ix, MemOpt opt, TileView tv, SwJob* jobs, int32_t* first_num, int32_t* counter, int cap)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= tv.n_reads) return;
+    int l_query, min_HSP_score, first = 0, cnt = 0;
+    if (rescore_read(ix, opt, tv, r, l_query, min_HSP_score)) {
+        const Chain* chains = tv.chains + tv.seed_off[r];
+        const int n_chn = tv.n_chains[r];
+        for (int pass = 0; pass < 2; ++pass) {             // count, reserve, write
+            int k = 0;
+            for (int i = 0; i < n_chn; ++i) {
+                const Chain c = chains[i];
+                const Seed* seeds = tv.cseeds + tv.seed_off[r] + c.seed0;
+                for (int j = 0; j < c.n; ++j) {
+                    int qb, qe; int64_t rb, re;
+                    if (!seed_sw_window(ix, l_query, seeds[j], qb, qe, rb, re)) continue;
+                    if (pass == 1 && k < cnt) {
+                        // ksw_align2(..., KSW_XSTART) in 16-bit mode; only the score of the first pass is used, so the job asks for that pass alone
+                        SwJob jb; jb.rb = rb; jb.read = r; jb.tag = k; jb.l_ms = qe - qb; jb.is_rev = 0; jb.tlen = (int)(re - rb); jb.xtra = 0; jb.q_off = qb; jb.pad_ = 0;
+                        jobs[first + k] = jb;
+                    }
+                    ++k;
+                }
+            }
+            if (pass == 0) {
+                cnt = k;
+                if (cnt > 0) { first = atomicAdd(counter, cnt); if (first + cnt > cap) { atomicOr(tv.err, ERR_JOB_CAP); cnt = 0; } }
+                if (cnt == 0) break;
+            }
+        }
+    }
+    first_num[r] = first; first_num[tv.n_reads + r] = cnt;
+}
+
+__global__ void k_rescore_apply(DevIndex ix, MemOpt opt, TileView tv, const KswR* results, const int32_t* first_num)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= tv.n_reads) return;
+    int l_query, min_HSP_score;
+    if (!rescore_read(ix, opt, tv, r, l_query, min_HSP_score)) return;
     const uint8_t* query = tv.seq + tv.seq_off[r];
-    int32_t hbuf[4 * (MEM_SHORT_LEN + 16)];
+    int q = first_num[r];
+    const int q_end = q + first_num[tv.n_reads + r];
+    int32_t hbuf[4 * (MEM_SHORT_LEN + 16)];               // (only used when a job was not run: list overflow, retried by the host)
     SwScratch W; W.cap_h = MEM_SHORT_LEN + 16; W.cap_b = 0; W.b = 0;
     W.H0 = hbuf; W.H1 = hbuf + W.cap_h; W.E = hbuf + 2 * W.cap_h; W.Hmax = hbuf + 3 * W.cap_h;
     Chain* chains = tv.chains + tv.seed_off[r];
+    const int n_chn = tv.n_chains[r];
     int err = 0;
     for (int i = 0; i < n_chn; ++i) {
         Chain& c = chains[i];
@@ -345,7 +390,17 @@ __global__ void k_rescore(DevIndex ix, MemOpt opt, TileView tv)
         int k = 0;
         for (int j = 0; j < c.n; ++j) {
             Seed s = seeds[j];
-            s.score = seed_sw(ix, opt, l_query, query, s, W, err);
+            int qb, qe; int64_t rb, re;
+            int sc = -1;
+            if (seed_sw_window(ix, l_query, s, qb, qe, rb, re)) {
+                sc = q < q_end ? results[q].score : (int)0x81818181;
+                ++q;
+                if (sc == (int)0x81818181) {
+                    SwIn I; I.ms = query + qb; I.l_ms = qe - qb; I.is_rev = 0; I.qrev = 0; I.t0 = rb; I.trev = 0;
+                    sc = sw_core(ix, opt, I, 2, qe - qb, (int)(re - rb), KSW_XSTART, W, err).score;
+                }
+            }
+            s.score = sc;
             if (s.score < 0 || s.score >= min_HSP_score) {
                 s.score = s.score < 0 ? s.len * opt.a : s.score;
                 seeds[k++] = s;
@@ -356,14 +411,20 @@ __global__ void k_rescore(DevIndex ix, MemOpt opt, TileView tv)
     if (err) atomicOr(tv.err, err);
 }
 
-void launch_rescore(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv)
-{
-    if (tv.n_reads <= 0) return;
-    // the shortest read that can trigger re-scoring has 5.5 ln L <= 0.05 L; skip the launch when no read of the tile can
+bool rescore_needed(const MemOpt& opt, const TileView& tv)
+{   // the shortest read that can trigger re-scoring has 5.5 ln L <= 0.05 L
     double L = tv.max_len > 1 ? (double)tv.max_len : 2.0;
     double min_l = opt.min_chain_weight ? 1.1f * opt.min_chain_weight : 5.5f * log(L);
-    if (min_l > 0.05f * L) return;
-    hipLaunchKernelGGL(k_rescore, dim3((tv.n_reads + 63) / 64), dim3(64), 0, st, ix, opt, tv);
+    return tv.n_reads > 0 && !(min_l > 0.05f * L);
+}
+
+void launch_rescore(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, void* jobs, void* results, int32_t* first_num, int32_t* cnt, int cap)
+{
+    if (!rescore_needed(opt, tv)) return;
+    (void)hipMemsetAsync(cnt, 0, 4, st);
+    hipLaunchKernelGGL(k_rescore_plan, dim3((tv.n_reads + 63) / 64), dim3(64), 0, st, ix, opt, tv, (SwJob*)jobs, first_num, cnt, cap);
+    launch_sw_jobs(st, ix, opt, tv, jobs, cnt, cap, results, 16, MEM_SHORT_LEN);
+    hipLaunchKernelGGL(k_rescore_apply, dim3((tv.n_reads + 63) / 64), dim3(64), 0, st, ix, opt, tv, (const KswR*)results, (const int32_t*)first_num);
 }
 
 void launch_chain(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, Chain* chain_store)

@@ -63,7 +63,8 @@ __global__ void k_pestat_cand(DevIndex ix, MemOpt opt, TileView tv, int8_t* cand
 // superset -- (2) k_pe_rescue_sw runs the listed alignments, four per wavefront, spread over the whole GPU, and
 // (3) k_pe_pair replays upstream's sequence and picks the results up.  A read with dozens of equally good hits makes
 // dozens of requests; done inside the pairing kernel they ran one after another while every other pair had long finished.
-struct RescueJob { int64_t rb; int32_t read, tag, l_ms, is_rev, tlen, xtra; };   // read: the mate (tile index); tag = end << 16 | anchor << 2 | orientation
+size_t pe_rescue_bytes(int what, int cap);
+typedef SwJob RescueJob;           // (bwamem_types.h) read: the mate (tile index); tag = end << 16 | anchor << 2 | orientation; q_off = 0
 #define RESCUE_NOT_RUN ((int)0x81818181)     // (the byte pattern the result array is preset with)
 
 // window and parameters of the rescue of `a`'s mate in orientation r (mem_matesw); false: no alignment for this orientation
@@ -298,7 +299,7 @@ __global__ void k_pe_rescue_plan(DevIndex ix, MemOpt opt, TileView tv, PeView pv
                     int is_rev, xtra; int64_t rb, re;
                     if (!rescue_req(ix, opt, pes, anc, r, c.l_seq[!i], rb, re, is_rev, xtra)) continue;
                     if (pass == 1 && k < cnt) {
-                        RescueJob jb; jb.rb = rb; jb.read = c.rd[!i]; jb.tag = i << 16 | j << 2 | r; jb.l_ms = c.l_seq[!i]; jb.is_rev = is_rev; jb.tlen = (int)(re - rb); jb.xtra = xtra;
+                        RescueJob jb; jb.rb = rb; jb.read = c.rd[!i]; jb.tag = i << 16 | j << 2 | r; jb.l_ms = c.l_seq[!i]; jb.is_rev = is_rev; jb.tlen = (int)(re - rb); jb.xtra = xtra; jb.q_off = 0; jb.pad_ = 0;
                         jobs[first + k] = jb;
                     }
                     ++k;
@@ -328,10 +329,10 @@ __global__ void __launch_bounds__(64) k_pe_rescue_sw(DevIndex ix, MemOpt opt, Ti
     if ((int)blockIdx.x * 4 >= n) return;
     const int job = blockIdx.x * 4 + (lane >> 4);
     const bool on = job < n;
-    RescueJob jb; jb.rb = 0; jb.read = 0; jb.tag = 0; jb.l_ms = 0; jb.is_rev = 0; jb.tlen = 0; jb.xtra = 0;
+    RescueJob jb; jb.rb = 0; jb.read = 0; jb.tag = 0; jb.l_ms = 0; jb.is_rev = 0; jb.tlen = 0; jb.xtra = 0; jb.q_off = 0; jb.pad_ = 0;
     if (on) jb = jobs[job];
     SwLds L; L.b = blists; L.cap_b = cap_b;
-    SwIn I; I.ms = tv.seq + tv.seq_off[jb.read]; I.l_ms = jb.l_ms; I.is_rev = jb.is_rev; I.qrev = 0; I.t0 = jb.rb; I.trev = 0;
+    SwIn I; I.ms = tv.seq + tv.seq_off[jb.read] + jb.q_off; I.l_ms = jb.l_ms; I.is_rev = jb.is_rev; I.qrev = 0; I.t0 = jb.rb; I.trev = 0;
     const bool u8 = (jb.xtra & KSW_XBYTE) != 0;
     const int p = u8 ? 16 : 8;
     const int slen = (jb.l_ms + p - 1) / p;
@@ -470,7 +471,7 @@ __global__ void k_pe_out(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPes
         MateInfo hm[2];
         int n_aa[2] = { 1, 1 }, alt_k[2] = { -1, -1 };
         for (int i = 0; i < 2; ++i) {
-            AlnRec h = reg2aln(ix, opt, S, l_seq[i], seq[i], &a[i][z[i]], jv);
+            AlnRec h = reg2aln(ix, opt, S, l_seq[i], seq[i], &a[i][z[i]], jv, true);
             hm[i] = mate_of(h);
             if (n_pri[i] < n[i]) {
                 const AlnReg* p = &a[i][n_pri[i]];
@@ -502,7 +503,7 @@ __global__ void k_pe_out(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPes
                 if (a[i][0].score >= opt.T) which = 0;
                 else if (n_pri[i] < n[i] && a[i][n_pri[i]].score >= opt.T) which = n_pri[i];
             }
-            AlnRec h = reg2aln(ix, opt, S, l_seq[i], seq[i], which >= 0 ? &a[i][which] : 0, jv);
+            AlnRec h = reg2aln(ix, opt, S, l_seq[i], seq[i], which >= 0 ? &a[i][which] : 0, jv, true);
             hm[i] = mate_of(h); hrid[i] = h.rid;
         }
         if (!(opt.flag & MEM_F_NOPAIRING) && hrid[0] == hrid[1] && hrid[0] >= 0) {
@@ -571,15 +572,19 @@ void launch_pe_pair(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const
     if (!(opt.flag & MEM_F_NO_RESCUE)) {
         hipLaunchKernelGGL(k_pe_rescue_plan, dim3((np + 127) / 128), dim3(128), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3],
                            (RescueJob*)rescue_jobs, rescue_first, rescue_num, rescue_cnt, rescue_cap);
-        (void)hipMemsetAsync(rescue_res, 0x81, pe_rescue_bytes(1, rescue_cap), st);          // every score = RESCUE_NOT_RUN until an instance writes it
-        hipLaunchKernelGGL((k_pe_rescue_sw<0, 10>), dim3((rescue_cap + 3) / 4), dim3(64), (size_t)4 * cap_b * 8, st, ix, opt, tv, (const RescueJob*)rescue_jobs, (const int32_t*)rescue_cnt, rescue_cap,
-                           (KswR*)rescue_res, cap_b);
-        if (tv.max_len > 80)
-            hipLaunchKernelGGL((k_pe_rescue_sw<10, 32>), dim3((rescue_cap + 3) / 4), dim3(64), (size_t)4 * cap_b * 8, st, ix, opt, tv, (const RescueJob*)rescue_jobs, (const int32_t*)rescue_cnt, rescue_cap,
-                               (KswR*)rescue_res, cap_b);
+        launch_sw_jobs(st, ix, opt, tv, rescue_jobs, rescue_cnt, rescue_cap, rescue_res, cap_b, tv.max_len);
     }
     hipLaunchKernelGGL(k_pe_pair, dim3((np + 63) / 64), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3], (PeState*)states,
                        (const RescueJob*)rescue_jobs, (const KswR*)rescue_res, (const int32_t*)rescue_first, (const int32_t*)rescue_num);
+}
+// ksw_align2 for a list of jobs (mate rescue, seed re-scoring); results preset to RESCUE_NOT_RUN, cnt = device job count
+void launch_sw_jobs(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, const void* jobs, const int32_t* cnt, int cap, void* results, int cap_b, int max_qlen)
+{
+    if (cap <= 0) return;
+    (void)hipMemsetAsync(results, 0x81, pe_rescue_bytes(1, cap), st);
+    hipLaunchKernelGGL((k_pe_rescue_sw<0, 10>), dim3((cap + 3) / 4), dim3(64), (size_t)4 * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b);
+    if (max_qlen > 80)
+        hipLaunchKernelGGL((k_pe_rescue_sw<10, 32>), dim3((cap + 3) / 4), dim3(64), (size_t)4 * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b);
 }
 size_t pe_rescue_bytes(int what, int cap) { return what == 0 ? (size_t)cap * sizeof(RescueJob) : (size_t)cap * sizeof(KswR); }
 void launch_pe_out(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, AlnReg* regs, const int64_t* reg_off,

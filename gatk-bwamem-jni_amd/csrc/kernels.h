@@ -9,7 +9,9 @@ void launch_seed(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const Ti
 void launch_scan(hipStream_t st, const int32_t* in, int64_t* out, int n);
 void launch_sa(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, int64_t n_occ);
 void launch_chain(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, Chain* chain_store);
-void launch_rescore(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
+// seed re-scoring (long reads): jobs/results sized by pe_rescue_bytes for `cap` >= the tile's seed count; first_num = 2 x n_reads ints, cnt = 1 int
+bool rescore_needed(const MemOpt& opt, const TileView& tv);
+void launch_rescore(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, void* jobs, void* results, int32_t* first_num, int32_t* cnt, int cap);
 void launch_extend(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 void launch_post1(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 void launch_final_prep(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
@@ -25,7 +27,8 @@ void launch_pe_copy_regs(hipStream_t st, const TileView& tv, const AlnReg* src, 
 void launch_pe_pair(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, AlnReg* regs, const int64_t* reg_off,
                     int32_t* n_regs, int32_t* ints, void* vpool, uint8_t* scratch, int64_t scratch_per_pair, int cap_h, int cap_b, int cap_u, const MemPestat* pes, void* states,
                     void* rescue_jobs, void* rescue_res, int32_t* rescue_first, int32_t* rescue_num, int32_t* rescue_cnt, int rescue_cap);
-size_t pe_rescue_bytes(int what, int cap);
+size_t pe_rescue_bytes(int what, int cap);       // what = 0: SwJob[cap], 1: KswR[cap]
+void launch_sw_jobs(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, const void* jobs, const int32_t* cnt, int cap, void* results, int cap_b, int max_qlen);
 void launch_pe_out(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, AlnReg* regs, const int64_t* reg_off,
                    int32_t* n_regs, int32_t* ints, const MemPestat* pes, const void* states, const void* job_out, const uint32_t* job_cig, int cig_cap);
 size_t pe_state_bytes(int n_reads);

@@ -473,7 +473,11 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
         }
         TIMED(ws, K_SA, launch_sa(ws.stream, ix->d, opt, tv, n_occ));
         TIMED(ws, K_CHAIN, launch_chain(ws.stream, ix->d, opt, tv, ws.chain_store.as<Chain>()));
-        TIMED(ws, K_CHAIN, launch_rescore(ws.stream, ix->d, opt, tv));
+        if (rescore_needed(opt, tv)) {                     // long reads: seed re-scoring jobs (at most one per seed occurrence)
+        const int rc = (int)std::min<int64_t>(n_occ + 16, 0x7fffffff);
+        if (!(ws.pe_rescue[0].ensure(pe_rescue_bytes(0, rc)) && ws.pe_rescue[1].ensure(pe_rescue_bytes(1, rc)) && ws.pe_rescue[2].ensure((size_t)T * 8 + 64))) return false;
+        TIMED(ws, K_CHAIN, launch_rescore(ws.stream, ix->d, opt, tv, ws.pe_rescue[0].p, ws.pe_rescue[1].p, ws.pe_rescue[2].as<int32_t>() + 16, ws.pe_rescue[2].as<int32_t>(), rc));
+    }
         TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
         if (getenv("BWAMEM_HIP_DUMP") && T <= 64) debug_dump(ws, tv, T);
         TIMED(ws, K_POST, launch_post1(ws.stream, ix->d, opt, tv));
@@ -640,7 +644,11 @@ static bool pe_phase1_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
     if (n_occ > ws.seed_cap) { PE_REQ(ws.ensure_seeds(n_occ + n_occ / 4)); tv = make_view(); }
     TIMED(ws, K_SA, launch_sa(ws.stream, ix->d, opt, tv, n_occ));
     TIMED(ws, K_CHAIN, launch_chain(ws.stream, ix->d, opt, tv, ws.chain_store.as<Chain>()));
-    TIMED(ws, K_CHAIN, launch_rescore(ws.stream, ix->d, opt, tv));
+    if (rescore_needed(opt, tv)) {                     // long reads: seed re-scoring jobs (at most one per seed occurrence)
+        const int rc = (int)std::min<int64_t>(n_occ + 16, 0x7fffffff);
+        if (!(ws.pe_rescue[0].ensure(pe_rescue_bytes(0, rc)) && ws.pe_rescue[1].ensure(pe_rescue_bytes(1, rc)) && ws.pe_rescue[2].ensure((size_t)T * 8 + 64))) return false;
+        TIMED(ws, K_CHAIN, launch_rescore(ws.stream, ix->d, opt, tv, ws.pe_rescue[0].p, ws.pe_rescue[1].p, ws.pe_rescue[2].as<int32_t>() + 16, ws.pe_rescue[2].as<int32_t>(), rc));
+    }
     TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
     TIMED(ws, K_POST, launch_post1(ws.stream, ix->d, opt, tv));
     pt->r0 = r0; pt->T = T; pt->L = L;

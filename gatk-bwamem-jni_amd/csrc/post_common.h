@@ -308,7 +308,9 @@ DEV bool region_needs_dp(const MemOpt& opt, const AlnReg& ar)
 }
 
 // mem_reg2aln; ar == 0 gives the unmapped record.  jv != 0: regions flagged in pad_ take their CIGAR from the job pool.
-DEV AlnRec reg2aln(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int l_query, const uint8_t* query, const AlnReg* ar, const JobView* jv = 0)
+// light: only position, strand, contig and reference span are wanted (the mate fields of the other read's record), so
+// the per-base NM / MD / score walks are skipped; NM, MD and mapq of the result are then not meaningful
+DEV AlnRec reg2aln(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int l_query, const uint8_t* query, const AlnReg* ar, const JobView* jv = 0, bool light = false)
 {
     AlnRec a;
     a.pos = 0; a.rid = 0; a.flag = 0; a.is_rev = 0; a.is_alt = 0; a.mapq = 0; a.NM = 0; a.n_cigar = 0;
@@ -331,7 +333,9 @@ DEV AlnRec reg2aln(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int l_
         const uint32_t* src = jv->cig + (size_t)job * jv->cig_cap;
         for (i = 0; i < n_cigar; ++i) S.cig[1 + i] = src[i];
         SeqAcc A; A.q = query + qb; A.qlen = qe - qb; A.rev = rb >= ix.l_pac; A.t0 = rb; A.tlen = (int)(re - rb);
-        cigar_nm_md(ix, S, A, n_cigar, rb < ix.l_pac, &NM, &l_md);
+        if (!light) cigar_nm_md(ix, S, A, n_cigar, rb < ix.l_pac, &NM, &l_md);
+    } else if (light && !region_needs_dp(opt, *ar) && !(qe - qb <= 0 || rb >= re || (rb < ix.l_pac && re > ix.l_pac) || re > ix.l_pac << 1)) {
+        S.cig[1] = (uint32_t)(qe - qb) << 4; n_cigar = 1;   // bwa_gen_cigar2's no-gap case: one M run
     } else {
         i = 0;
         do {

@@ -11,7 +11,6 @@
 #define KSW_XSUBO  0x40000
 #define KSW_XSTART 0x80000
 
-struct KswR { int score, te, qe, score2, te2, tb, qb; };
 
 struct SwIn {
     const uint8_t* ms; int l_ms; int is_rev;     // query = ms or its reverse complement
