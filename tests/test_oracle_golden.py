@@ -78,3 +78,32 @@ def test_threads_do_not_change_results(oracle, rota_img):
     four = oracle.align_raw(h, B.set_opt(oracle.default_options(), n_threads=4), req)
     oracle.destroy_index(h)
     assert one == four
+
+
+def test_oracle_slice_entry_point_and_response_walker(oracle, rota_img):
+    """checker utilities used by bench.py: oracle_createAlignmentsAt(read_id0 = 0) is oracle_createAlignments, and the C
+    response walker finds the same record boundaries as the Python one"""
+    import ctypes
+    reads = [b"GGCTTTTAATGCTTTTCAGTGGTTGCTGCTCAAGATGGAGTCTACTCAGCAGATGGTAAGCTCTATTATT",
+             b"AATACTTCTTTTGAAGCTGCAGTTGTTGCTGCCTTCAACATTAGAATTAATGGGTATTCAATATGATT", b"ACGT" * 20, b"N" * 30, b""]
+    h = oracle.open_index(rota_img)
+    opts = oracle.default_options()
+    req = B.pack_request(reads)
+    want = oracle.align_raw(h, opts, req)
+    fn = oracle.dll.oracle_createAlignmentsAt
+    fn.restype = ctypes.c_void_p
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_int64]
+    rb = ctypes.create_string_buffer(req, len(req)); sz = ctypes.c_size_t()
+    ob = ctypes.create_string_buffer(bytes(opts), B.OPT_SIZE)
+    p = fn(h, ob, None, rb, ctypes.byref(sz), 0)
+    assert ctypes.string_at(p, sz.value) == want
+    oracle._free(p)
+    offs = (ctypes.c_int64 * (len(reads) + 1))()
+    ro = oracle.dll.oracle_response_offsets
+    ro.restype = ctypes.c_int
+    ro.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p]
+    assert ro(want, len(want), len(reads), offs) == 0
+    parts = B.split_response(want, len(reads))
+    assert [offs[i + 1] - offs[i] for i in range(len(reads))] == [len(x) for x in parts]
+    assert ro(want, len(want) - 1, len(reads), offs) == -1           # truncated buffer is reported
+    oracle.destroy_index(h)
