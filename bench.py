@@ -339,7 +339,9 @@ def main():
         tcpu = time.time() - tc
         orc.destroy_index(ho)
         rb = ctypes.create_string_buffer(req, len(req)); sz = ctypes.c_size_t()
+        tj = time.time()
         gp = lib.jnibwa_createAlignments(idx, opts, None, rb, ctypes.byref(sz))
+        tj = time.time() - tj
         got = ctypes.string_at(gp, sz.value) if gp else None
         if gp:
             lib.jnibwa_free(gp)
@@ -368,6 +370,8 @@ def main():
         out["cpu_baseline"] = {"value": S / tcpu, "unit": "reads/s", "cores": cores, "kind": "port",
                                "sample": "first %d reads of the same batch through oracle/ (own CPU restatement, not libbwa), %d threads, %.1f s" % (S, cores, tcpu)}
         out["parity_sample"] = {"reads": S, "frac_identical_records": ident}
+        # the drop-in entry point itself on the same sample: host request in, host response out (upload, alignment, download)
+        out["jni_call_host_to_host"] = {"reads": S, "reads_per_s": S / tj if tj > 0 else None, "note": "jnibwa_createAlignments, PCIe both ways included; never `value`"}
         if tail is not None:
             out["parity_sample_tail"] = tail
 

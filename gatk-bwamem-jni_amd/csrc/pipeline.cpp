@@ -547,7 +547,9 @@ static bool run_tiles_seeded(bwaidx_s* ix, const MemOpt& opt, bwamem_batch_s* b,
         for (size_t i = 0; i < specs.size(); ++i) {
             const int64_t n_new = chunks.empty() ? 0 : (int64_t)(specs[i].r1 - chunks.back().r0);
             const int L_new = chunks.empty() ? 1 : std::max(chunks.back().L, specs[i].L);
-            if (chunks.empty() || n_new > (int64_t)chunk_reads || n_new * std::max(64, L_new + 8) * 36 > budget) {
+            // the first chunks are small (one tile, then two, ...) so that the tile workers start early; the tiles behind them overlap the big ones
+            const int64_t ramp = std::min<int64_t>((int64_t)chunk_reads, (int64_t)(specs[0].r1 - specs[0].r0) << std::min<size_t>(chunks.empty() ? 0 : chunks.size() - 1, 8));
+            if (chunks.empty() || n_new > ramp || n_new * std::max(64, L_new + 8) * 36 > budget) {
                 SeedChunk c; c.r0 = specs[i].r0; c.tile0 = i; c.L = 1;
                 chunks.push_back(c);
             }
