@@ -61,7 +61,8 @@ enum {
 // this halves its cost.  40-bit counts cover texts up to 2^40 symbols.
 struct DevIndex {
     const uint4* occ;          // 2 x uint4 per 64-symbol block: {C, G, T low words, high bytes}, {sym[4]}
-    const uint64_t* sa;        // sampled every sa_intv ranks; sa[0] = (u64)-1
+    const uint32_t* sa_lo;     // suffix array, 40 bits per entry (low word / high byte), kept for every sa_intv-th rank:
+    const uint8_t*  sa_hi;     // densified from the image's sampling at load time (k_sa_densify); entry 0 = -1
     const uint8_t*  pac;       // 2 bit/base, first base in the two MSBs
     const int64_t*  ann_offset;
     const int32_t*  ann_len;
@@ -71,7 +72,7 @@ struct DevIndex {
     const double*   log_tab;   // glibc log(i) for i in [0, log_tab_n): libm stays on the host
     uint64_t primary, L2[5], seq_len;
     int64_t  l_pac;
-    int32_t  n_seqs, sa_intv, log_tab_n, pad_;
+    int32_t  n_seqs, sa_intv, log_tab_n, sa_shift;   // sa_intv = 1 << sa_shift
 };
 
 struct Intv { uint64_t x0, x1, size, info; };          // info = start<<32 | end

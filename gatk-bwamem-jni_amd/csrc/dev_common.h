@@ -103,29 +103,36 @@ DEV void set_intv(const DevIndex& ix, int c, Intv& ik)
     ik.info = 0;
 }
 
-// text position of rank k: LF-walk to the next sampled rank (row a7); n_lf counts the steps
+// bwt_invPsi: the rank of the suffix that starts one text position before the suffix of rank k
+DEV uint64_t lf_step(const DevIndex& ix, uint64_t k)
+{
+    if (k == ix.primary) return 0;
+    const uint64_t x = k - (k > ix.primary), b = x >> 6;
+    const uint4* p = ix.occ + 2 * b;
+    const uint4 cv = p[0], s = p[1];
+    const int off = (int)(x & 63);
+    const uint32_t w = (off >> 4) == 0 ? s.x : (off >> 4) == 1 ? s.y : (off >> 4) == 2 ? s.z : s.w;
+    const int c = (int)(w >> ((~off & 15) << 1) & 3);           // BWT symbol at rank k
+    uint32_t c1 = 0, c2 = 0, c3 = 0;
+    cnt_word(s.x, off + 1, c1, c2, c3);  cnt_word(s.y, off - 15, c1, c2, c3);
+    cnt_word(s.z, off - 31, c1, c2, c3); cnt_word(s.w, off - 47, c1, c2, c3);
+    uint64_t a0, a1, a2, a3;
+    occ_unpack(cv, b, a0, a1, a2, a3);
+    const uint64_t base = c == 0 ? a0 : c == 1 ? a1 : c == 2 ? a2 : a3;
+    const uint32_t add = c == 0 ? (uint32_t)(off + 1 - (int)(c1 + c2 + c3)) : c == 1 ? c1 : c == 2 ? c2 : c3;
+    return ix.L2[c] + base + add;
+}
+
+// text position of rank k: LF-walk to the next stored rank (row a7); n_lf counts the steps.  With the suffix array
+// densified to every rank (the default when HBM allows, see upload_index) the walk is empty and this is one gather
 DEV uint64_t sa_lookup(const DevIndex& ix, uint64_t k, uint32_t& n_lf)
 {
-    uint64_t sa = 0, mask = (uint64_t)ix.sa_intv - 1;
-    while (k & mask) {
-        ++sa; ++n_lf;
-        if (k == ix.primary) { k = 0; continue; }
-        const uint64_t x = k - (k > ix.primary), b = x >> 6;
-        const uint4* p = ix.occ + 2 * b;
-        const uint4 cv = p[0], s = p[1];
-        const int off = (int)(x & 63);
-        const uint32_t w = (off >> 4) == 0 ? s.x : (off >> 4) == 1 ? s.y : (off >> 4) == 2 ? s.z : s.w;
-        const int c = (int)(w >> ((~off & 15) << 1) & 3);       // BWT symbol at rank k
-        uint32_t c1 = 0, c2 = 0, c3 = 0;
-        cnt_word(s.x, off + 1, c1, c2, c3);  cnt_word(s.y, off - 15, c1, c2, c3);
-        cnt_word(s.z, off - 31, c1, c2, c3); cnt_word(s.w, off - 47, c1, c2, c3);
-        uint64_t a0, a1, a2, a3;
-        occ_unpack(cv, b, a0, a1, a2, a3);
-        const uint64_t base = c == 0 ? a0 : c == 1 ? a1 : c == 2 ? a2 : a3;
-        const uint32_t add = c == 0 ? (uint32_t)(off + 1 - (int)(c1 + c2 + c3)) : c == 1 ? c1 : c == 2 ? c2 : c3;
-        k = ix.L2[c] + base + add;
-    }
-    return sa + ix.sa[k / (uint64_t)ix.sa_intv];
+    uint64_t sa = 0;
+    const uint64_t mask = (uint64_t)ix.sa_intv - 1;
+    while (k & mask) { ++sa; ++n_lf; k = lf_step(ix, k); }
+    const uint64_t e = k >> ix.sa_shift;
+    const uint64_t v = (uint64_t)ix.sa_lo[e] | (uint64_t)ix.sa_hi[e] << 32;
+    return sa + (uint64_t)((int64_t)(v << 24) >> 24);           // 40-bit two's complement: entry 0 is -1
 }
 
 // ---------------------------------------------------------------- reference access (U8)
@@ -287,7 +294,7 @@ DEV void ks_combsort(size_t n, T* a, LT lt)
 template <typename T, typename LT>
 DEV void ks_introsort(size_t n, T* a, LT lt)
 {
-    struct Frame { T* left; T* right; int depth; };
+    struct Frame { int left, right, depth; };        // offsets from a, not pointers: a pointer reloaded from private memory loses its address space (flat accesses)
     Frame stack[66];
     int sp = 0;
     if (n < 1) return;
@@ -319,17 +326,17 @@ DEV void ks_introsort(size_t n, T* a, LT lt)
                 }
                 { T tmp = *i; *i = *t; *t = tmp; }
                 if (i - s > t - i) {
-                    if (i - s > 16) { stack[sp].left = s; stack[sp].right = i - 1; stack[sp].depth = d; ++sp; }
+                    if (i - s > 16) { stack[sp].left = (int)(s - a); stack[sp].right = (int)(i - 1 - a); stack[sp].depth = d; ++sp; }
                     s = t - i > 16 ? i + 1 : t;
                 } else {
-                    if (t - i > 16) { stack[sp].left = i + 1; stack[sp].right = t; stack[sp].depth = d; ++sp; }
+                    if (t - i > 16) { stack[sp].left = (int)(i + 1 - a); stack[sp].right = (int)(t - a); stack[sp].depth = d; ++sp; }
                     t = i - s > 16 ? i - 1 : s;
                 }
             }
         } else if (sp == 0) {
             ks_insertsort(a, a + n, lt);
             done = true;
-        } else { --sp; s = stack[sp].left; t = stack[sp].right; d = stack[sp].depth; }
+        } else { --sp; s = a + stack[sp].left; t = a + stack[sp].right; d = stack[sp].depth; }
     }
 }
 

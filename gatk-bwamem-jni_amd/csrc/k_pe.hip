@@ -451,73 +451,101 @@ __global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPe
     if (S.err | err) atomicOr(tv.err, S.err | err);
 }
 
-// mem_sam_pe, second half (one lane per pair): the records of both mates
+// mem_sam_pe, second half: the records of both mates.  One lane per read (lanes 2k and 2k+1 hold the mates of a pair):
+// nothing at this stage writes to the regions, so a mate only needs the other's position summary (a `light` reg2aln of
+// the other mate's chosen region, recomputed here rather than exchanged) and the two records are otherwise independent --
+// twice the waves and half the dependent chain of a lane-per-pair layout, which is what this latency-bound stage wants
 __global__ void k_pe_out(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3, const PeState* states, JobView jvv)
 {
-    int pi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pi >= tv.n_reads >> 1) return;
-    const MemPestat pes[4] = { p0, p1, p2, p3 };
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= (tv.n_reads & ~1)) return;
+    const int pi = r >> 1, i = r & 1, m = r ^ 1;
     const JobView* jv = &jvv;
-    PeCtx c = pe_ctx(tv, pv, pi);
-    const int* rd = c.rd; const uint8_t** seq = c.seq; int* l_seq = c.l_seq; AlnReg** a = c.a; int* n = c.n; int32_t** zb = c.zb;
-    PostScratch S = post_scratch_for(tv, rd[0]);
-    OutBuf ob[2];
-    for (int i = 0; i < 2; ++i) { ob[i].p = tv.out + (size_t)rd[i] * tv.out_cap; ob[i].cap = tv.out_cap; ob[i].len = 0; ob[i].ovf = false; }
+    // own read / mate: plain pointers derived from the kernel arguments (no pointer arrays: a pointer reloaded from
+    // private memory loses its address space and every access through it becomes a flat access -- on this
+    // latency-bound stage that alone was a factor of three)
+    const uint8_t* seq_i = tv.seq + tv.seq_off[r];
+    const uint8_t* seq_m = tv.seq + tv.seq_off[m];
+    const int l_i = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1), l_m = (int)(tv.seq_off[m + 1] - tv.seq_off[m] - 1);
+    const AlnReg* ai = pv.regs + pv.reg_off[r];
+    const AlnReg* am = pv.regs + pv.reg_off[m];
+    const int n_i = pv.n_regs[r], n_m = pv.n_regs[m];
+    int32_t* zb_i = pv.ints + 2 * pv.reg_off[r];
+    PostScratch S = post_scratch_for(tv, r);
+    OutBuf ob;
+    ob.p = tv.out + (size_t)r * tv.out_cap; ob.cap = tv.out_cap; ob.len = 0; ob.ovf = false;
     const PeState st = states[pi];
-    const int z[2] = { st.z0, st.z1 }, n_pri[2] = { st.n_pri0, st.n_pri1 }, q_se[2] = { st.q_se0, st.q_se1 };
+    const int z_i = i ? st.z1 : st.z0, z_m = i ? st.z0 : st.z1, npri_i = i ? st.n_pri1 : st.n_pri0, npri_m = i ? st.n_pri0 : st.n_pri1;
+    const int q_se_i = i ? st.q_se1 : st.q_se0;
     int extra_flag = st.extra_flag;
-    if (st.paired) {
-        // records: h[i] (+ an ALT supplementary g[i]); each needs the mate's position
-        MateInfo hm[2];
-        int n_aa[2] = { 1, 1 }, alt_k[2] = { -1, -1 };
-        for (int i = 0; i < 2; ++i) {
-            AlnRec h = reg2aln(ix, opt, S, l_seq[i], seq[i], &a[i][z[i]], jv, true);
-            hm[i] = mate_of(h);
-            if (n_pri[i] < n[i]) {
-                const AlnReg* p = &a[i][n_pri[i]];
-                if (!(p->score < opt.T || p->secondary >= 0 || !p->is_alt)) { alt_k[i] = n_pri[i]; n_aa[i] = 2; }
-            }
+    const bool paired = st.paired != 0;
+    // Both outcomes of the pairing stage (the pair's records h/g, or each end through mem_reg2sam) run through the same
+    // two loops below -- mate summary, then records -- so that a wave holding both kinds of pairs executes the per-base
+    // work (reg2aln, aln2out) once, not once per kind.
+    // 1. the mate's position summary (and, for the unpaired case, this end's contig for the proper-pair flag)
+    MateInfo mate; mate.rid = -1; mate.pos = -1; mate.is_rev = 0; mate.ref_len = 0;
+    int rid_i = -1, rid_m = -1;
+    for (int k = 0; k < 2; ++k) {                               // k = 0: the mate, k = 1: this end
+        if (paired && k == 1) break;                            // h of this end is written below
+        const AlnReg* ak = k ? ai : am;
+        const int nk = k ? n_i : n_m, nprik = k ? npri_i : npri_m;
+        const AlnReg* sel = 0;
+        if (paired) sel = &ak[z_m];
+        else if (nk) {
+            if (ak[0].score >= opt.T) sel = &ak[0];
+            else if (nprik < nk && ak[nprik].score >= opt.T) sel = &ak[nprik];
         }
-        for (int i = 0; i < 2; ++i) {
-            int32_t *cnt = 0, *has_alt = 0;
-            if (!(opt.flag & MEM_F_ALL) && n[i] > 0) {
-                cnt = zb[i]; has_alt = zb[i] + n[i];
-                if (xa_prepare(opt, n[i], a[i], cnt, has_alt) == 0) cnt = has_alt = 0;
-            }
-            AlnRec h = reg2aln(ix, opt, S, l_seq[i], seq[i], &a[i][z[i]], jv);
-            h.mapq = q_se[i];
-            h.flag |= 0x40 << i | extra_flag;
-            aln2out(ix, opt, S, ob[i], n_aa[i], 0, h, &hm[!i], l_seq[i], seq[i], n[i], a[i], cnt, has_alt, cnt ? z[i] : -1, jv);
-            if (alt_k[i] >= 0) {
-                AlnRec g = reg2aln(ix, opt, S, l_seq[i], seq[i], &a[i][alt_k[i]], jv);
-                g.flag |= 0x800 | 0x40 << i | extra_flag;
-                aln2out(ix, opt, S, ob[i], n_aa[i], 1, g, &hm[!i], l_seq[i], seq[i], n[i], a[i], cnt, has_alt, cnt ? alt_k[i] : -1, jv);
-            }
-        }
-    } else {                                                    // no_pairing
-        MateInfo hm[2];
-        int hrid[2];
-        for (int i = 0; i < 2; ++i) {
-            int which = -1;
-            if (n[i]) {
-                if (a[i][0].score >= opt.T) which = 0;
-                else if (n_pri[i] < n[i] && a[i][n_pri[i]].score >= opt.T) which = n_pri[i];
-            }
-            AlnRec h = reg2aln(ix, opt, S, l_seq[i], seq[i], which >= 0 ? &a[i][which] : 0, jv, true);
-            hm[i] = mate_of(h); hrid[i] = h.rid;
-        }
-        if (!(opt.flag & MEM_F_NOPAIRING) && hrid[0] == hrid[1] && hrid[0] >= 0) {
+        AlnRec h = reg2aln(ix, opt, S, k ? l_i : l_m, k ? seq_i : seq_m, sel, jv, true);
+        if (k) rid_i = h.rid; else { mate = mate_of(h); rid_m = h.rid; }
+    }
+    if (!paired) {
+        if (!(opt.flag & MEM_F_NOPAIRING) && rid_i == rid_m && rid_i >= 0) {
             int64_t dist;
-            int d = infer_dir(ix.l_pac, a[0][0].rb, a[1][0].rb, &dist);
-            if (!pes[d].failed && dist >= pes[d].low && dist <= pes[d].high) extra_flag |= 2;
+            const int64_t rb0 = i ? am[0].rb : ai[0].rb, rb1 = i ? ai[0].rb : am[0].rb;
+            const int d = infer_dir(ix.l_pac, rb0, rb1, &dist);
+            const MemPestat pd = d == 0 ? p0 : d == 1 ? p1 : d == 2 ? p2 : p3;
+            if (!pd.failed && dist >= pd.low && dist <= pd.high) extra_flag |= 2;
         }
-        reg2sam(ix, opt, S, ob[0], l_seq[0], seq[0], n[0], a[0], zb[0], 0x41 | extra_flag, &hm[1], jv);
-        reg2sam(ix, opt, S, ob[1], l_seq[1], seq[1], n[1], a[1], zb[1], 0x81 | extra_flag, &hm[0], jv);
+        extra_flag |= i ? 0x81 : 0x41;
     }
-    for (int i = 0; i < 2; ++i) {
-        tv.out_len[rd[i]] = ob[i].ovf ? 0 : ob[i].len;
-        if (ob[i].ovf) atomicOr(tv.err, ERR_OUT_CAP);
+    // 2. which regions become records: h = z and the ALT supplementary g (paired), or mem_reg2sam's selection
+    int alt_k = -1;
+    if (paired && npri_i < n_i) {
+        const AlnReg* p = &ai[npri_i];
+        if (!(p->score < opt.T || p->secondary >= 0 || !p->is_alt)) alt_k = npri_i;
     }
+    int32_t *cnt = 0, *has_alt = 0;
+    if (!(opt.flag & MEM_F_ALL) && n_i > 0) {
+        cnt = zb_i; has_alt = zb_i + n_i;
+        if (xa_prepare(opt, n_i, ai, cnt, has_alt) == 0) cnt = has_alt = 0;
+    }
+    int n_aa = 0;
+    for (int k = 0; k < n_i; ++k) n_aa += paired ? (k == z_i || k == alt_k) : reg2sam_selects(opt, ai, k);
+    if (n_aa == 0) {                                            // unpaired only: h always exists for a paired end
+        AlnRec t = reg2aln(ix, opt, S, l_i, seq_i, 0);
+        t.flag |= extra_flag;
+        aln2out(ix, opt, S, ob, 1, 0, t, &mate, l_i, seq_i, n_i, ai, 0, 0, -1);
+    }
+    int l = 0, mapq0 = 0;
+    for (int k = 0; k < n_i && n_aa; ++k) {
+        if (!(paired ? (k == z_i || k == alt_k) : reg2sam_selects(opt, ai, k))) continue;
+        const AlnReg* p = &ai[k];
+        AlnRec q = reg2aln(ix, opt, S, l_i, seq_i, p, jv);
+        if (paired) {
+            if (k == z_i) q.mapq = q_se_i; else q.flag |= 0x800;
+            q.flag |= 0x40 << i | extra_flag;
+        } else {
+            q.flag |= extra_flag;
+            if (p->secondary >= 0) q.sub = -1;
+            if (l && p->secondary < 0) q.flag |= (opt.flag & MEM_F_NO_MULTI) ? 0x10000 : 0x800;
+            if (l && !p->is_alt && q.mapq > mapq0) q.mapq = mapq0;
+            if (l == 0) mapq0 = q.mapq;
+        }
+        aln2out(ix, opt, S, ob, n_aa, l, q, &mate, l_i, seq_i, n_i, ai, cnt, has_alt, cnt ? k : -1, jv);
+        ++l;
+    }
+    tv.out_len[r] = ob.ovf ? 0 : ob.len;
+    if (ob.ovf) atomicOr(tv.err, ERR_OUT_CAP);
     if (S.err) atomicOr(tv.err, S.err);
 }
 
@@ -595,6 +623,6 @@ void launch_pe_out(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const 
     PeView pv; pv.vpool = 0; pv.scratch = 0; pv.scratch_per_pair = 0; pv.cap_h = pv.cap_b = pv.cap_u = 0;
     pv.regs = regs; pv.reg_off = reg_off; pv.n_regs = n_regs; pv.ints = ints;
     JobView jv; jv.out = (const DpOut*)job_out; jv.cig = job_cig; jv.cig_cap = cig_cap;
-    hipLaunchKernelGGL(k_pe_out, dim3((np + 63) / 64), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3], (const PeState*)states, jv);
+    hipLaunchKernelGGL(k_pe_out, dim3((2 * np + 63) / 64), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3], (const PeState*)states, jv);
 }
 size_t pe_state_bytes(int n_reads) { return (size_t)((n_reads >> 1) + 1) * sizeof(PeState); }

@@ -30,9 +30,9 @@ __global__ void k_post1(DevIndex ix, MemOpt opt, TileView tv)
             return;
         }
     }
-    if (tv.debug) printf("[k] post1 read %d n=%d\n", r, tv.n_regs[r]);
-    int n = sort_dedup_patch(ix, opt, S, query, tv.n_regs[r], a, tv.debug);
-    if (tv.debug) printf("[k] post1 read %d done n=%d\n", r, n);
+    if (tv.debug & 0xff) printf("[k] post1 read %d n=%d\n", r, tv.n_regs[r]);
+    int n = sort_dedup_patch(ix, opt, S, query, tv.n_regs[r], a, tv.debug & 0xff);
+    if (tv.debug & 0xff) printf("[k] post1 read %d done n=%d\n", r, n);
     for (int i = 0; i < n; ++i)
         if (a[i].rid >= 0 && ix.ann_is_alt[a[i].rid]) a[i].is_alt = 1;
     tv.n_regs[r] = n;

@@ -426,6 +426,35 @@ __global__ void k_sa(DevIndex ix, MemOpt opt, TileView tv, int64_t n_occ)
     if ((threadIdx.x & 63) == 0) { count_add(&tv.cnt->n_lf, a); count_add(&tv.cnt->n_sa, b); }
 }
 
+// Suffix-array densification at index load.  The image samples SA at every src_intv-th rank, which makes a lookup an
+// LF-walk of geometrically distributed length (mean src_intv - 1 dependent occurrence-table gathers, the slowest lane of
+// a wave several times that).  HBM has room for much more: walking LF from a sampled rank visits ranks whose text
+// position decreases by one per step until the next sampled rank, and those walks partition the unsampled ranks (LF
+// is a permutation), so one lane per sampled rank fills the whole array in seq_len steps in total.  Entries are kept
+// for every ix.sa_intv-th rank (ix.sa_intv divides src_intv), 40 bits each.
+__global__ void k_sa_densify(DevIndex ix, const uint64_t* sa_src, uint64_t n_src, int src_intv, uint32_t* lo, uint8_t* hi, int32_t* err)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_src) return;
+    uint64_t k = t * (uint64_t)src_intv, v = sa_src[t];
+    lo[k >> ix.sa_shift] = (uint32_t)v; hi[k >> ix.sa_shift] = (uint8_t)(v >> 32);
+    if (ix.sa_intv == src_intv) return;
+    if (t == 0) v = ix.seq_len;                                  // rank 0 is the empty suffix (stored as -1 upstream)
+    const uint64_t smask = (uint64_t)src_intv - 1, dmask = (uint64_t)ix.sa_intv - 1;
+    for (uint64_t step = 0; ; ++step) {
+        if (step > ix.seq_len) { atomicOr(err, ERR_SCRATCH); return; }   // not a permutation: corrupt index
+        k = lf_step(ix, k);
+        if (!(k & smask)) return;
+        --v;
+        if (!(k & dmask)) { lo[k >> ix.sa_shift] = (uint32_t)v; hi[k >> ix.sa_shift] = (uint8_t)(v >> 32); }
+    }
+}
+
+void launch_sa_densify(hipStream_t st, const DevIndex& ix, const uint64_t* sa_src, uint64_t n_src, int src_intv, uint32_t* lo, uint8_t* hi, int32_t* err)
+{
+    hipLaunchKernelGGL(k_sa_densify, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, st, ix, sa_src, n_src, src_intv, lo, hi, err);
+}
+
 // image occ/bwt layout (128-symbol blocks: 4 x u64 counts + 8 x u32 symbols) -> device layout (see bwamem_types.h)
 __global__ void k_build_occ64(const uint32_t* bwt, uint64_t n_blocks, uint4* occ)
 {

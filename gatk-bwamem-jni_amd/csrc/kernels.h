@@ -4,6 +4,8 @@
 #include "bwamem_types.h"
 
 void launch_build_occ64(hipStream_t st, const uint32_t* bwt, uint64_t n_blocks, uint4* occ);
+// suffix array at every ix.sa_intv-th rank (lo/hi, (seq_len >> sa_shift) + 1 entries) from the image's sampling; *err: device int, OR-ed on failure
+void launch_sa_densify(hipStream_t st, const DevIndex& ix, const uint64_t* sa_src, uint64_t n_src, int src_intv, uint32_t* lo, uint8_t* hi, int32_t* err);
 void launch_encode(hipStream_t st, uint8_t* seq, int64_t n_bytes);
 void launch_seed(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 void launch_scan(hipStream_t st, const int32_t* in, int64_t* out, int n);

@@ -141,7 +141,7 @@ struct bwaidx_s {
     HostIndex h;
     int device = 0;
     DevIndex d;
-    DevBuf d_occ, d_sa, d_pac, d_ann_off, d_ann_len, d_ann_alt, d_name_off, d_names, d_log;
+    DevBuf d_occ, d_sa_lo, d_sa_hi, d_pac, d_ann_off, d_ann_len, d_ann_alt, d_name_off, d_names, d_log;
     std::mutex mu;                  // one call at a time per index/device
     Workspace ws;
     std::vector<Workspace*> extra_ws;   // further tiles in flight (one stream + host thread each)
@@ -180,8 +180,7 @@ static bool upload_index(bwaidx_s* ix)
         HIP_OK(hipDeviceSynchronize());
         tmp.release();
     }
-    if (!ix->d_sa.ensure((size_t)h.n_sa * 8) || !ix->d_pac.ensure((size_t)(h.l_pac / 4 + 1) + 16)) return false;
-    HIP_OK(hipMemcpy(ix->d_sa.p, h.sa, (size_t)h.n_sa * 8, hipMemcpyHostToDevice));
+    if (!ix->d_pac.ensure((size_t)(h.l_pac / 4 + 1) + 16)) return false;
     HIP_OK(hipMemcpy(ix->d_pac.p, h.pac, (size_t)(h.l_pac / 4 + 1), hipMemcpyHostToDevice));
     std::vector<int64_t> off(n); std::vector<int32_t> len(n), alt(n), noff(n + 1);
     std::string names;
@@ -205,18 +204,40 @@ static bool upload_index(bwaidx_s* ix)
     }
     DevIndex& d = ix->d;
     memset(&d, 0, sizeof d);
-    d.occ = ix->d_occ.as<uint4>(); d.sa = ix->d_sa.as<uint64_t>(); d.pac = ix->d_pac.as<uint8_t>();
+    d.occ = ix->d_occ.as<uint4>(); d.pac = ix->d_pac.as<uint8_t>();
     d.ann_offset = ix->d_ann_off.as<int64_t>(); d.ann_len = ix->d_ann_len.as<int32_t>(); d.ann_is_alt = ix->d_ann_alt.as<int32_t>();
     d.ann_name_off = ix->d_name_off.as<int32_t>(); d.names = ix->d_names.as<char>(); d.log_tab = ix->d_log.as<double>();
     d.primary = h.primary; for (int i = 0; i < 5; ++i) d.L2[i] = h.L2[i];
-    d.seq_len = h.seq_len; d.l_pac = h.l_pac; d.n_seqs = n; d.sa_intv = h.sa_intv; d.log_tab_n = LOG_TAB_N;
+    d.seq_len = h.seq_len; d.l_pac = h.l_pac; d.n_seqs = n; d.log_tab_n = LOG_TAB_N;
+    {   // suffix array: the image samples every h.sa_intv-th rank; keep it as dense as HBM comfortably allows (5 bytes per
+        // kept rank, at most a quarter of what is free now), so that a lookup is a short LF-walk or none at all
+        int dense = 1;
+        if (const char* e = getenv("BWAMEM_HIP_SA_INTV")) { dense = atoi(e); if (dense < 1 || (dense & (dense - 1))) dense = 1; }
+        size_t free_b = 0, total_b = 0;
+        HIP_OK(hipMemGetInfo(&free_b, &total_b));
+        if (dense > h.sa_intv) dense = h.sa_intv;
+        while (dense < h.sa_intv && ((size_t)(h.seq_len / dense) + 1) * 5 + (size_t)h.n_sa * 8 > free_b / 4) dense <<= 1;
+        d.sa_intv = dense; d.sa_shift = 0;
+        while ((1 << d.sa_shift) < dense) ++d.sa_shift;
+        const size_t n_kept = (size_t)(h.seq_len >> d.sa_shift) + 1;
+        DevBuf src, flag;
+        if (!ix->d_sa_lo.ensure(n_kept * 4 + 64) || !ix->d_sa_hi.ensure(n_kept + 64) || !src.ensure((size_t)h.n_sa * 8) || !flag.ensure(64)) { src.release(); flag.release(); return false; }
+        d.sa_lo = ix->d_sa_lo.as<uint32_t>(); d.sa_hi = ix->d_sa_hi.as<uint8_t>();
+        int32_t bad = 1;
+        if (hipMemcpy(src.p, h.sa, (size_t)h.n_sa * 8, hipMemcpyHostToDevice) == hipSuccess && hipMemset(flag.p, 0, 64) == hipSuccess) {
+            launch_sa_densify(0, d, src.as<uint64_t>(), h.n_sa, h.sa_intv, ix->d_sa_lo.as<uint32_t>(), ix->d_sa_hi.as<uint8_t>(), flag.as<int32_t>());
+            if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&bad, flag.p, 4, hipMemcpyDeviceToHost) != hipSuccess) bad = 1;
+        }
+        src.release(); flag.release();
+        if (bad) { fprintf(stderr, "[bwamem_hip] suffix array densification failed\n"); return false; }
+    }
     return true;
 }
 
 static void free_index(bwaidx_s* ix)
 {
     (void)hipSetDevice(ix->device);
-    DevBuf* all[] = { &ix->d_occ, &ix->d_sa, &ix->d_pac, &ix->d_ann_off, &ix->d_ann_len, &ix->d_ann_alt, &ix->d_name_off, &ix->d_names, &ix->d_log };
+    DevBuf* all[] = { &ix->d_occ, &ix->d_sa_lo, &ix->d_sa_hi, &ix->d_pac, &ix->d_ann_off, &ix->d_ann_len, &ix->d_ann_alt, &ix->d_name_off, &ix->d_names, &ix->d_log };
     for (DevBuf* b : all) b->release();
     ix->ws.release();
     ix->seed_ws.release();

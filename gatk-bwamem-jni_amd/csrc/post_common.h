@@ -97,7 +97,7 @@ DEV int acc_t_c(const DevIndex& ix, const SeqAcc& A, SeqCache& c, int i)
 DEV int acc_q_c(const SeqAcc& A, SeqCache& c, int j)
 {
     const uint8_t* a = A.q + (A.rev ? A.qlen - 1 - j : j);
-    const uint32_t* wp = (const uint32_t*)((uintptr_t)a & ~(uintptr_t)3);
+    const uint32_t* wp = (const uint32_t*)(a - ((uintptr_t)a & 3));      // pointer arithmetic, not an integer round trip: keeps the address space (global loads, not flat)
     if (wp != c.qp) { c.qp = wp; c.qv = *wp; }
     return (int)(c.qv >> (((uintptr_t)a & 3) << 3) & 0xffu);
 }
@@ -634,6 +634,16 @@ DEV void aln2out(const DevIndex& ix, const MemOpt& opt, PostScratch& S, OutBuf& 
     }
 }
 
+// mem_reg2sam's record selection (conditions use regions only)
+DEV bool reg2sam_selects(const MemOpt& opt, const AlnReg* a, int k)
+{
+    const AlnReg* p = &a[k];
+    if (p->score < opt.T) return false;
+    if (p->secondary >= 0 && (p->is_alt || !(opt.flag & MEM_F_ALL))) return false;
+    if (p->secondary >= 0 && p->secondary < INT_MAX_ && (float)p->score < (float)a[p->secondary].score * opt.drop_ratio) return false;
+    return true;
+}
+
 // mem_reg2sam: select the records of one read and write them
 DEV void reg2sam(const DevIndex& ix, const MemOpt& opt, PostScratch& S, OutBuf& ob, int l_query, const uint8_t* query,
                  int n, AlnReg* a, int32_t* zbuf, int extra_flag, const MateInfo* m, const JobView* jv = 0)
@@ -644,13 +654,7 @@ DEV void reg2sam(const DevIndex& ix, const MemOpt& opt, PostScratch& S, OutBuf& 
         if (xa_prepare(opt, n, a, cnt, has_alt) == 0) cnt = has_alt = 0;
     }
     int n_aa = 0;
-    for (int k = 0; k < n; ++k) {                       // selection pass (conditions use regions only)
-        const AlnReg* p = &a[k];
-        if (p->score < opt.T) continue;
-        if (p->secondary >= 0 && (p->is_alt || !(opt.flag & MEM_F_ALL))) continue;
-        if (p->secondary >= 0 && p->secondary < INT_MAX_ && (float)p->score < (float)a[p->secondary].score * opt.drop_ratio) continue;
-        ++n_aa;
-    }
+    for (int k = 0; k < n; ++k) n_aa += reg2sam_selects(opt, a, k);
     if (n_aa == 0) {
         AlnRec t = reg2aln(ix, opt, S, l_query, query, 0);
         t.flag |= extra_flag;
@@ -659,10 +663,8 @@ DEV void reg2sam(const DevIndex& ix, const MemOpt& opt, PostScratch& S, OutBuf& 
     }
     int l = 0, mapq0 = 0;
     for (int k = 0; k < n; ++k) {
+        if (!reg2sam_selects(opt, a, k)) continue;
         const AlnReg* p = &a[k];
-        if (p->score < opt.T) continue;
-        if (p->secondary >= 0 && (p->is_alt || !(opt.flag & MEM_F_ALL))) continue;
-        if (p->secondary >= 0 && p->secondary < INT_MAX_ && (float)p->score < (float)a[p->secondary].score * opt.drop_ratio) continue;
         AlnRec q = reg2aln(ix, opt, S, l_query, query, p, jv);
         q.flag |= extra_flag;
         if (p->secondary >= 0) q.sub = -1;
