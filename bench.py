@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=600_000, help="reads timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--paired", action="store_true", help="auxiliary measurement (BASELINE.json config 2): --reads is then the number of reads = 2 x pairs; "
                     "the library infers the insert-size statistics per call; metric/roofline fields are still reported for the seeding kernel")
+    ap.add_argument("--pestat", default=None, help="with --paired: LOW,HIGH,AVG,STD of the FR insert size supplied by the caller (BwaMemAligner's "
+                    "proper-pair statistics) instead of inferred per call; the call is then a single pass over the tiles")
     ap.add_argument("--keep-image", default=None, help="also copy the index image to this path (profiling helper)")
     ap.add_argument("--dump-request", default=None, help="write the first --cpu-sample reads as a request file (profiling helper)")
     ap.add_argument("--image", default=None, help="use an existing .img (e.g. GATK's Homo_sapiens_assembly38.fasta.img) instead of the synthetic genome")
@@ -224,8 +226,13 @@ def main():
     if args.paired:
         struct.pack_into("<i", opts, 60, struct.unpack_from("<i", opts, 60)[0] | 0x2 | int(os.environ.get("BENCH_EXTRA_FLAG", "0"), 0))   # mem_opt_t.flag |= MEM_F_PE
 
+    pes = None
+    if args.paired and args.pestat:
+        lo, hi, avg, std = args.pestat.split(",")
+        pes = b"".join(struct.pack("<iiiidd", int(lo), int(hi), 0, 0, float(avg), float(std)) if i == 1 else struct.pack("<iiiidd", 0, 0, 1, 0, 0.0, 0.0) for i in range(4))
+
     def step():
-        if lib.bwamem_hip_batch_align(idx, opts, None, batch, rank * R) != 0:
+        if lib.bwamem_hip_batch_align(idx, opts, pes, batch, rank * R) != 0:
             raise SystemExit("align failed")
 
     def barrier():
@@ -250,7 +257,7 @@ def main():
     st_timed = Stats(); lib.bwamem_hip_stats_get(ctypes.byref(st_timed))
     # keep the records of the LAST reads of the timed batch (four tiles and a seeding chunk in flight) for the parity check below
     tail_bytes, S2 = None, 0
-    if rank == 0 and world == 1 and args.cpu_sample > 0 and not args.paired:     # (paired: the batch-wide insert-size statistics differ from a slice's)
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and (not args.paired or pes is not None):   # (paired with inferred statistics: the batch-wide ones differ from a slice's)
         import bwalib as B
         if not os.path.exists(B.ORACLE_LIB):
             B.build_oracle()
@@ -309,9 +316,9 @@ def main():
             "metric": "150bp reads aligned/sec vs GRCh38-scale reference (1/2/4/8 MI355X)", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32/int64", "data": "synthetic",
-            "config": {"workload": "%d x %dbp single-end synthetic reads per GPU vs synthetic GRCh38-scale genome (%d bp, %d contigs, 5%% diverged repeats), full index in HBM" % (R, L, args.genome_bp, args.contigs),
+            "config": {"workload": "%d x %dbp %s synthetic reads per GPU vs synthetic GRCh38-scale genome (%d bp, %d contigs, 5%% diverged repeats), full index in HBM" % (R, L, "paired-end (2 x %d pairs)" % (R // 2) if args.paired else "single-end", args.genome_bp, args.contigs),
                        "reads_per_gpu": R, "read_len": L, "genome_bp": args.genome_bp, "index_build_s": round(t_index, 1), "response_bytes": result_bytes,
-                       "parallelism": "read-sharded x%d, no collectives" % world, "paired_end": bool(args.paired)},
+                       "parallelism": "read-sharded x%d, no collectives" % world, "paired_end": bool(args.paired), "insert_size_statistics": ("supplied " + args.pestat) if (args.paired and args.pestat) else ("inferred per call" if args.paired else None)},
             "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_note, "measured_in": "extra untimed step with nothing else on the GPU: one tile in flight, seeding chunks not overlapped (see DESIGN.md section 5)", "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": int(st.n_launch_seed),
                          "n_ext_per_read": st.n_ext / max(1, st.n_reads)},
@@ -335,12 +342,12 @@ def main():
         if args.paired:
             B.set_opt(oo, flag=B.get_opt(oo, "flag") | B.MEM_F_PE)
         tc = time.time()
-        want = orc.align_raw(ho, oo, req)
+        want = orc.align_raw(ho, oo, req, pes)
         tcpu = time.time() - tc
         orc.destroy_index(ho)
         rb = ctypes.create_string_buffer(req, len(req)); sz = ctypes.c_size_t()
         tj = time.time()
-        gp = lib.jnibwa_createAlignments(idx, opts, None, rb, ctypes.byref(sz))
+        gp = lib.jnibwa_createAlignments(idx, opts, pes, rb, ctypes.byref(sz))
         tj = time.time() - tj
         got = ctypes.string_at(gp, sz.value) if gp else None
         if gp:
@@ -361,7 +368,7 @@ def main():
             ho2 = orc.open_index(img)
             rb2 = ctypes.create_string_buffer(req2, len(req2)); sz2 = ctypes.c_size_t()
             ob2 = ctypes.create_string_buffer(bytes(oo), 168)
-            p2 = fn(ho2, ob2, None, rb2, ctypes.byref(sz2), rank * R + R - S2)
+            p2 = fn(ho2, ob2, pes, rb2, ctypes.byref(sz2), rank * R + R - S2)
             want2 = ctypes.string_at(p2, sz2.value) if p2 else None
             orc.destroy_index(ho2)
             if want2 is not None:

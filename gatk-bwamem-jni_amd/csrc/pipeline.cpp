@@ -341,26 +341,49 @@ static void debug_dump(Workspace& ws, const TileView& tv, int T)
 //  -- and phase 2 (per tile) does mate rescue, pairing and record generation.
 
 static void host_pestat(const MemOpt& opt, const std::vector<int8_t>& dir, const std::vector<int64_t>& is, MemPestat pes[4])
-{   // upstream mem_pestat after candidate collection (bwamem_pair.c); candidates arrive in pair order
-    std::vector<uint64_t> isize[4];
-    for (size_t i = 0; i < dir.size(); ++i) if (dir[i] >= 0) isize[(int)dir[i]].push_back((uint64_t)is[i]);
+{   // upstream mem_pestat after candidate collection (bwamem_pair.c).  Upstream sorts each orientation's insert sizes and
+    // walks the sorted array; candidates are bounded by opt.max_ins, so the sorted array is represented by a histogram
+    // (value -> multiplicity) and walked in the same order -- the same percentiles and the same sequence of double
+    // additions, without an O(n log n) host sort of millions of values between the two phases of a call
+    uint64_t vmax = 0;
+    for (size_t i = 0; i < dir.size(); ++i) if (dir[i] >= 0 && (uint64_t)is[i] > vmax) vmax = (uint64_t)is[i];
+    const bool use_hist = vmax < ((uint64_t)1 << 22);
+    std::vector<uint64_t> isize[4];                 // sorted values (fallback) ...
+    std::vector<uint32_t> hist[4];                  // ... or multiplicities
+    size_t n_of[4] = { 0, 0, 0, 0 };
+    if (use_hist) {
+        for (int d = 0; d < 4; ++d) hist[d].assign((size_t)vmax + 1, 0);
+        for (size_t i = 0; i < dir.size(); ++i) if (dir[i] >= 0) { ++hist[(int)dir[i]][(size_t)is[i]]; ++n_of[(int)dir[i]]; }
+    } else {
+        for (size_t i = 0; i < dir.size(); ++i) if (dir[i] >= 0) isize[(int)dir[i]].push_back((uint64_t)is[i]);
+        for (int d = 0; d < 4; ++d) { std::sort(isize[d].begin(), isize[d].end()); n_of[d] = isize[d].size(); }
+    }
     memset(pes, 0, 4 * sizeof(MemPestat));
     for (int d = 0; d < 4; ++d) {
         MemPestat* r = &pes[d];
-        std::vector<uint64_t>& q = isize[d];
-        if (q.size() < 10) { r->failed = 1; continue; }
-        std::sort(q.begin(), q.end());
-        int p25 = (int)q[(int)(.25 * q.size() + .499)];
-        int p75 = (int)q[(int)(.75 * q.size() + .499)];
+        const size_t n = n_of[d];
+        if (n < 10) { r->failed = 1; continue; }
+        auto at = [&](size_t k) -> uint64_t {        // k-th smallest
+            if (!use_hist) return isize[d][k];
+            size_t c = 0;
+            for (size_t v = 0; v < hist[d].size(); ++v) { c += hist[d][v]; if (c > k) return (uint64_t)v; }
+            return vmax;
+        };
+        auto walk = [&](auto&& f) {                  // every value, ascending, with multiplicity
+            if (!use_hist) { for (uint64_t v : isize[d]) f(v); return; }
+            for (size_t v = 0; v < hist[d].size(); ++v) for (uint32_t c = hist[d][v]; c; --c) f((uint64_t)v);
+        };
+        int p25 = (int)at((size_t)(int)(.25 * n + .499));
+        int p75 = (int)at((size_t)(int)(.75 * n + .499));
         r->low = (int)(p25 - 2.0 * (p75 - p25) + .499);
         if (r->low < 1) r->low = 1;
         r->high = (int)(p75 + 2.0 * (p75 - p25) + .499);
         size_t x = 0;
         r->avg = 0;
-        for (size_t i = 0; i < q.size(); ++i) if (q[i] >= (uint64_t)r->low && q[i] <= (uint64_t)r->high) { r->avg += q[i]; ++x; }
+        walk([&](uint64_t v) { if (v >= (uint64_t)r->low && v <= (uint64_t)r->high) { r->avg += v; ++x; } });
         r->avg /= x;
         r->std = 0;
-        for (size_t i = 0; i < q.size(); ++i) if (q[i] >= (uint64_t)r->low && q[i] <= (uint64_t)r->high) r->std += (q[i] - r->avg) * (q[i] - r->avg);
+        walk([&](uint64_t v) { if (v >= (uint64_t)r->low && v <= (uint64_t)r->high) r->std += (v - r->avg) * (v - r->avg); });
         r->std = sqrt(r->std / x);
         r->low  = (int)(p25 - 3.0 * (p75 - p25) + .499);
         r->high = (int)(p75 + 3.0 * (p75 - p25) + .499);
@@ -369,8 +392,8 @@ static void host_pestat(const MemOpt& opt, const std::vector<int8_t>& dir, const
         if (r->low < 1) r->low = 1;
     }
     size_t mx = 0;
-    for (int d = 0; d < 4; ++d) mx = std::max(mx, isize[d].size());
-    for (int d = 0; d < 4; ++d) if (pes[d].failed == 0 && isize[d].size() < mx * 0.05) pes[d].failed = 1;
+    for (int d = 0; d < 4; ++d) mx = std::max(mx, n_of[d]);
+    for (int d = 0; d < 4; ++d) if (pes[d].failed == 0 && n_of[d] < mx * 0.05) pes[d].failed = 1;
 }
 
 static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes0, bwamem_batch_s* b, int64_t read_id0);
@@ -796,14 +819,24 @@ static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes
     std::vector<PeTile> tiles(specs.size());
     auto cleanup = [&]() { for (PeTile& t : tiles) { t.n_regs.release(); t.regs.release(); t.reg_off.release(); } };
     b->tiles.assign(specs.size(), TileOut());
-    // ---------------- phase 1
+    // ---------------- phase 1 (seeding .. regions per read).  The insert-size statistics are a property of the whole call,
+    // so when they have to be inferred every tile must finish phase 1 before any can start phase 2; when the caller
+    // supplies them (pes0) a tile goes straight on to phase 2 on the same worker and the call is a single pass
     if (!run_tiles_seeded(ix, opt, b, specs, [&](Workspace& w, size_t i, const SeedStore& store, uint32_t chunk_r0) {
-            return pe_phase1_tile(ix, w, opt, b, read_id0, specs[i], &tiles[i], store, chunk_r0, pes0 == nullptr);
+            if (!pe_phase1_tile(ix, w, opt, b, read_id0, specs[i], &tiles[i], store, chunk_r0, pes0 == nullptr)) return false;
+            if (!pes0) return true;
+            const bool ok = pe_phase2_tile(ix, w, opt, b, read_id0, &tiles[i], pes0, b->tiles[i]);
+            tiles[i].n_regs.release(); tiles[i].regs.release(); tiles[i].reg_off.release();
+            return ok;
         })) { cleanup(); return false; }
+    if (pes0) {
+        for (const TileOut& t : b->tiles) b->result_bytes += t.bytes;
+        cleanup();
+        return true;
+    }
     // ---------------- insert-size statistics (candidates in pair order)
     MemPestat pes[4];
-    if (pes0) memcpy(pes, pes0, sizeof pes);
-    else {
+    {
         std::vector<int8_t> cand_dir; std::vector<int64_t> cand_is;
         for (PeTile& t : tiles) { cand_dir.insert(cand_dir.end(), t.cand_dir.begin(), t.cand_dir.end()); cand_is.insert(cand_is.end(), t.cand_is.begin(), t.cand_is.end()); }
         host_pestat(opt, cand_dir, cand_is, pes);

@@ -37,12 +37,19 @@ struct OutBuf {
     __device__ void put32(int32_t v) { if (len + 4 > cap) { ovf = true; return; } *(int32_t*)(p + len) = v; len += 4; }
     __device__ void putc(char c) { if (len + 1 > cap) { ovf = true; return; } p[len++] = (uint8_t)c; }
     __device__ void pad4() { while (len & 3) putc(0); }
+    // decimal digits through a register (16 BCD nibbles), not a private array: dynamically indexed private arrays live in scratch memory
+    __device__ void put_digits(unsigned long x, int min_digits) {
+        unsigned long bcd = 0; int l = 0;
+        if (x >> 32) do { bcd |= (x % 10) << (l << 2); ++l; x /= 10; } while (x);
+        else { unsigned y = (unsigned)x; do { bcd |= (unsigned long)(y % 10u) << (l << 2); ++l; y /= 10u; } while (y); }
+        l = l > min_digits ? l : min_digits;
+        while (l > 0) { --l; putc((char)('0' + (int)(bcd >> (l << 2) & 15ul))); }
+    }
     __device__ void putl(long v) {
-        char b[24]; int l = 0;
-        unsigned long x = v < 0 ? 0ul - (unsigned long)v : (unsigned long)v;
-        do { b[l++] = (char)('0' + x % 10); x /= 10; } while (x);
-        if (v < 0) b[l++] = '-';
-        while (l > 0) putc(b[--l]);
+        const unsigned long x = v < 0 ? 0ul - (unsigned long)v : (unsigned long)v, e16 = 10000000000000000ul;
+        if (v < 0) putc('-');
+        if (x >= e16) { put_digits(x / e16, 1); put_digits(x % e16, 16); }
+        else put_digits(x, 1);
     }
 };
 
@@ -50,11 +57,11 @@ struct MdBuf {
     char* s; int cap, l; bool ovf;
     __device__ void putc(char c) { if (l + 1 >= cap) { ovf = true; return; } s[l++] = c; }
     __device__ void putw(int v) {
-        char b[16]; int n = 0;
         unsigned x = v < 0 ? 0u - (unsigned)v : (unsigned)v;
-        do { b[n++] = (char)('0' + x % 10); x /= 10; } while (x);
-        if (v < 0) b[n++] = '-';
-        while (n > 0) putc(b[--n]);
+        unsigned long bcd = 0; int n = 0;
+        do { bcd |= (unsigned long)(x % 10u) << (n << 2); ++n; x /= 10u; } while (x);
+        if (v < 0) putc('-');
+        while (n > 0) { --n; putc((char)('0' + (int)(bcd >> (n << 2) & 15ul))); }
     }
 };
 
