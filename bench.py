@@ -86,15 +86,15 @@ def synth_genome(torch, dev, total_bp, n_contigs, seed):
 
 
 def synth_pairs(torch, dev, codes, contigs, n_pairs, length, seed):
-    """config 2 of BASELINE.json: FR pairs, insert size ~ N(300, 30) clipped to [length, 600]; mates interleaved as Java sends them."""
+    """config 2 of BASELINE.json (cfg 3 there): FR pairs, insert size ~ N(400, 50^2) clipped to [length, 1000]; mates interleaved as Java sends them."""
     g = torch.Generator(device=dev); g.manual_seed(seed ^ 0x9E37)
     total = codes.numel()
-    span = 640 + length
+    span = 1040 + length
     bounds = torch.tensor([0] + [l for _, l in contigs], device=dev).cumsum(0)
     pos1 = (torch.rand(n_pairs, generator=g, device=dev, dtype=torch.float64) * (total - span)).long()
     ci = torch.searchsorted(bounds, pos1, right=True) - 1
     pos1 = torch.where(pos1 + span <= bounds[ci + 1], pos1, torch.clamp(bounds[ci + 1] - span, min=0))
-    isize = torch.clamp((torch.randn(n_pairs, generator=g, device=dev) * 30 + 300).long(), min=length, max=600)
+    isize = torch.clamp((torch.randn(n_pairs, generator=g, device=dev) * 50 + 400).long(), min=length, max=1000)
     pos2 = pos1 + isize - length
     fs = torch.rand(n_pairs, generator=g, device=dev) < 0.5
     r1 = synth_reads(torch, dev, codes, contigs, n_pairs, length, seed, pos=torch.where(fs, pos1, pos2), rc=~fs)

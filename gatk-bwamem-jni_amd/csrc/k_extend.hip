@@ -507,10 +507,15 @@ __global__ void __launch_bounds__(64, K_EXTEND_MIN_WAVES) k_extend(DevIndex ix, 
     }
 }
 
+// LDS of one k_extend workgroup for reads of up to max_len bases: the H, E and M rows of the general form + the read
+size_t extend_lds_bytes(int max_len)
+{
+    size_t cap = (size_t)max_len + 2;
+    return 3 * cap * sizeof(int32_t) + ((cap + 15) & ~(size_t)15);
+}
 void launch_extend(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv)
 {
     if (tv.n_reads <= 0) return;
-    size_t cap = (size_t)tv.max_len + 2;
-    size_t shmem = 3 * cap * sizeof(int32_t) + ((cap + 15) & ~(size_t)15);
+    size_t shmem = extend_lds_bytes(tv.max_len);
     hipLaunchKernelGGL(k_extend, dim3(tv.n_reads), dim3(64), shmem, st, ix, opt, tv);
 }

@@ -159,6 +159,7 @@ struct bwamem_batch_s {
     std::vector<int64_t> h_off;
     std::vector<TileOut> tiles;
     size_t result_bytes = 0;
+    struct PeCall* pe = nullptr;    // paired-end call split in two steps (bwamem_hip_batch_pe_begin / _finish): phase-1 products kept in HBM
 };
 
 static const int LOG_TAB_N = 1 << 20;
@@ -293,7 +294,10 @@ static void verbose_sync(Workspace& ws, const char* what)
     fflush(stderr);
     t_last = t1; (void)t_last;
 }
-#define TIMED(ws, id, call) do { timed_begin(ws, id); call; timed_end(ws); if (verbose()) verbose_sync(ws, #call); } while (0)
+// every launch is checked: a launch the device refuses (e.g. more LDS than a CU has) must fail the call, not leave stale buffers behind
+#define TIMED(ws, id, call) do { timed_begin(ws, id); call; timed_end(ws); \
+    { hipError_t le_ = hipGetLastError(); if (le_ != hipSuccess) { fprintf(stderr, "[bwamem_hip] launch failed: %s (%s)\n", hipGetErrorString(le_), #call); return false; } } \
+    if (verbose()) verbose_sync(ws, #call); } while (0)
 
 // ------------------------------------------------------------------------------------------ tile loop
 // per-read scratch of the one-lane-per-read post stages: (h,e) row, CIGAR, MD and -- only where the scalar global
@@ -332,6 +336,21 @@ static void debug_dump(Workspace& ws, const TileView& tv, int T)
                     rg[i].qb, rg[i].qe, rg[i].rid, rg[i].score, rg[i].truesc, rg[i].w, rg[i].seedcov, rg[i].seedlen0);
     }
     fflush(stderr);
+}
+
+// Longest read the device path takes: the packed candidate format of the seeding kernel holds 17-bit positions, and the
+// general (LDS-row) form of the extension kernel keeps three int32 rows and the read of one workgroup in LDS
+// (13 bytes per base: about 12 500 bases with the 160 KB of a gfx950 CU).  Longer reads fail the call with a message.
+static bool read_length_ok(const bwaidx_s* ix, int L)
+{
+    if (L >= (1 << 17) - 1) { fprintf(stderr, "[bwamem_hip] reads of 131071 bases or more are not supported\n"); return false; }
+    int lds = 0;
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, ix->device) != hipSuccess || lds <= 0) lds = 64 << 10;
+    if (extend_lds_bytes(L) > (size_t)lds) {
+        fprintf(stderr, "[bwamem_hip] a read of %d bases needs %zu bytes of LDS for the extension rows, the device offers %d: reads this long are not supported yet\n", L, extend_lds_bytes(L), lds);
+        return false;
+    }
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------ paired-end flow
@@ -812,81 +831,116 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
 #undef PE_OK
 #undef PE_REQ
 
-static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes0, bwamem_batch_s* b, int64_t read_id0)
+// what phase 1 of a paired-end call leaves behind for phase 2
+struct PeCall { std::vector<TileSpec> specs; std::vector<PeTile> tiles; int64_t read_id0 = 0; };
+static void pe_call_free(bwamem_batch_s* b)
 {
-    const std::vector<TileSpec> specs = plan_tiles(b, opt, true, false);
-    for (const TileSpec& t : specs) if (t.L >= (1 << 17) - 1) { fprintf(stderr, "[bwamem_hip] reads of 131071 bases or more are not supported\n"); return false; }
-    std::vector<PeTile> tiles(specs.size());
-    auto cleanup = [&]() { for (PeTile& t : tiles) { t.n_regs.release(); t.regs.release(); t.reg_off.release(); } };
+    if (!b->pe) return;
+    for (PeTile& t : b->pe->tiles) { t.n_regs.release(); t.regs.release(); t.reg_off.release(); }
+    delete b->pe; b->pe = nullptr;
+}
+
+// phase 1 over all tiles (seeding .. regions per read).  The insert-size statistics are a property of the whole call,
+// so when they have to be inferred every tile must finish phase 1 before any can start phase 2; when the caller
+// supplies them (pes0) a tile goes straight on to phase 2 on the same worker and the call is a single pass
+static bool pe_begin(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes0, bwamem_batch_s* b, int64_t read_id0)
+{
+    pe_call_free(b);
+    PeCall* pc = b->pe = new PeCall();
+    pc->read_id0 = read_id0;
+    pc->specs = plan_tiles(b, opt, true, false);
+    const std::vector<TileSpec>& specs = pc->specs;
+    for (const TileSpec& t : specs) if (!read_length_ok(ix, t.L)) { pe_call_free(b); return false; }
+    pc->tiles.resize(specs.size());
+    std::vector<PeTile>& tiles = pc->tiles;
     b->tiles.assign(specs.size(), TileOut());
-    // ---------------- phase 1 (seeding .. regions per read).  The insert-size statistics are a property of the whole call,
-    // so when they have to be inferred every tile must finish phase 1 before any can start phase 2; when the caller
-    // supplies them (pes0) a tile goes straight on to phase 2 on the same worker and the call is a single pass
     if (!run_tiles_seeded(ix, opt, b, specs, [&](Workspace& w, size_t i, const SeedStore& store, uint32_t chunk_r0) {
             if (!pe_phase1_tile(ix, w, opt, b, read_id0, specs[i], &tiles[i], store, chunk_r0, pes0 == nullptr)) return false;
             if (!pes0) return true;
             const bool ok = pe_phase2_tile(ix, w, opt, b, read_id0, &tiles[i], pes0, b->tiles[i]);
             tiles[i].n_regs.release(); tiles[i].regs.release(); tiles[i].reg_off.release();
             return ok;
-        })) { cleanup(); return false; }
+        })) { pe_call_free(b); return false; }
     if (pes0) {
         for (const TileOut& t : b->tiles) b->result_bytes += t.bytes;
-        cleanup();
-        return true;
+        pe_call_free(b);
     }
-    // ---------------- insert-size statistics (candidates in pair order)
+    return true;
+}
+
+// phase 2 (mate rescue, pairing, records) with the statistics of the whole call: tiles in flight on the worker streams
+static bool pe_finish(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, bwamem_batch_s* b)
+{
+    if (!b->pe) return false;
+    const std::vector<TileSpec>& specs = b->pe->specs;
+    std::vector<PeTile>& tiles = b->pe->tiles;
+    const int64_t read_id0 = b->pe->read_id0;
+    const char* env_s = getenv("BWAMEM_HIP_STREAMS");
+    const int n_workers = std::max(1, std::min<int>((int)specs.size(), env_s ? atoi(env_s) : 4));
+    while ((int)ix->extra_ws.size() < n_workers - 1) ix->extra_ws.push_back(new Workspace());
+    std::atomic<size_t> next(0);
+    std::atomic<bool> failed(false);
+    auto worker = [&](int k) {
+        Workspace& w = k == 0 ? ix->ws : *ix->extra_ws[k - 1];
+        if (hipSetDevice(ix->device) != hipSuccess) { failed = true; return; }
+        if (!w.stream && hipStreamCreate(&w.stream) != hipSuccess) { failed = true; return; }
+        while (!failed) {
+            const size_t i = next++;
+            if (i >= specs.size()) break;
+            if (!pe_phase2_tile(ix, w, opt, b, read_id0, &tiles[i], pes, b->tiles[i])) failed = true;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_workers; ++k) th.emplace_back(worker, k);
+    worker(0);
+    for (std::thread& t : th) t.join();
+    if (!failed) for (const TileOut& t : b->tiles) b->result_bytes += t.bytes;
+    pe_call_free(b);
+    return !failed;
+}
+
+// the (orientation, insert size) candidates of the pairs of this call / shard, in pair order
+static void pe_candidates(const bwamem_batch_s* b, std::vector<int8_t>& dir, std::vector<int64_t>& is)
+{
+    dir.clear(); is.clear();
+    if (!b->pe) return;
+    for (const PeTile& t : b->pe->tiles) { dir.insert(dir.end(), t.cand_dir.begin(), t.cand_dir.end()); is.insert(is.end(), t.cand_is.begin(), t.cand_is.end()); }
+}
+
+static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes0, bwamem_batch_s* b, int64_t read_id0)
+{
+    if (!pe_begin(ix, opt, pes0, b, read_id0)) return false;
+    if (pes0) return true;
     MemPestat pes[4];
     {
         std::vector<int8_t> cand_dir; std::vector<int64_t> cand_is;
-        for (PeTile& t : tiles) { cand_dir.insert(cand_dir.end(), t.cand_dir.begin(), t.cand_dir.end()); cand_is.insert(cand_is.end(), t.cand_is.begin(), t.cand_is.end()); }
+        pe_candidates(b, cand_dir, cand_is);
         host_pestat(opt, cand_dir, cand_is, pes);
     }
-    // ---------------- phase 2: tiles in flight on the same worker streams
-    {
-        const char* env_s = getenv("BWAMEM_HIP_STREAMS");
-        const int n_workers = std::max(1, std::min<int>((int)specs.size(), env_s ? atoi(env_s) : 4));
-        while ((int)ix->extra_ws.size() < n_workers - 1) ix->extra_ws.push_back(new Workspace());
-        std::atomic<size_t> next(0);
-        std::atomic<bool> failed(false);
-        auto worker = [&](int k) {
-            Workspace& w = k == 0 ? ix->ws : *ix->extra_ws[k - 1];
-            if (hipSetDevice(ix->device) != hipSuccess) { failed = true; return; }
-            if (!w.stream && hipStreamCreate(&w.stream) != hipSuccess) { failed = true; return; }
-            while (!failed) {
-                const size_t i = next++;
-                if (i >= specs.size()) break;
-                if (!pe_phase2_tile(ix, w, opt, b, read_id0, &tiles[i], pes, b->tiles[i])) failed = true;
-            }
-        };
-        std::vector<std::thread> th;
-        for (int k = 1; k < n_workers; ++k) th.emplace_back(worker, k);
-        worker(0);
-        for (std::thread& t : th) t.join();
-        if (failed) { cleanup(); return false; }
-    }
-    for (const TileOut& t : b->tiles) b->result_bytes += t.bytes;
-    cleanup();
-    return true;
+    return pe_finish(ix, opt, pes, b);
 }
 
 // Tiles are independent, and every kernel of a tile ends in a tail of a few long-running reads; several tiles are
 // therefore kept in flight on separate HIP streams (one host thread + workspace each) so that one tile's tail
 // overlaps the next tile's bulk.
-static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, bwamem_batch_s* b, int64_t read_id0)
+// pe_step = 1: only phase 1 of a paired-end call (bwamem_hip_batch_pe_begin)
+static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, bwamem_batch_s* b, int64_t read_id0, int pe_step = 0)
 {
     HIP_OK(hipSetDevice(ix->device));
     Workspace& ws = ix->ws;
     if (!ws.stream) HIP_OK(hipStreamCreate(&ws.stream));
     for (TileOut& t : b->tiles) if (t.d) (void)hipFree(t.d);
     b->tiles.clear(); b->result_bytes = 0;
+    pe_call_free(b);
     if (b->n_reads == 0) return true;
     HIP_OK(hipMemcpyAsync(b->d_seq.p, b->d_raw.p, b->n_bytes, hipMemcpyDeviceToDevice, ws.stream));
     TIMED(ws, K_ENCODE, launch_encode(ws.stream, b->d_seq.as<uint8_t>(), (int64_t)b->n_bytes));
     HIP_OK(hipStreamSynchronize(ws.stream));
     timed_collect(ws);
+    if (pe_step == 1) return pe_begin(ix, opt, nullptr, b, read_id0);
     if (opt.flag & MEM_F_PE) return align_batch_pe(ix, opt, pes, b, read_id0);
     const std::vector<TileSpec> specs = plan_tiles(b, opt, false, false);
-    for (const TileSpec& t : specs) if (t.L >= (1 << 17) - 1) { fprintf(stderr, "[bwamem_hip] reads of 131071 bases or more are not supported\n"); return false; }
+    for (const TileSpec& t : specs) if (!read_length_ok(ix, t.L)) return false;
     b->tiles.assign(specs.size(), TileOut());
     if (!run_tiles_seeded(ix, opt, b, specs, [&](Workspace& w, size_t i, const SeedStore& store, uint32_t chunk_r0) {
             return run_tile_se(ix, w, opt, b, read_id0, specs[i], b->tiles[i], store, chunk_r0, w.out_cap_hint);
@@ -1042,6 +1096,40 @@ int bwamem_hip_batch_align(bwaidx_t* idx, const mem_opt_t* opt, const mem_pestat
     return align_batch(idx, o, (const MemPestat*)pes, b, read_id0) ? 0 : -1;
 }
 
+int bwamem_hip_batch_pe_begin(bwaidx_t* idx, const mem_opt_t* opt, bwamem_batch_t* b, int64_t read_id0)
+{
+    if (!idx || !opt || !b) return -1;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    MemOpt o; memcpy(&o, opt, sizeof o);
+    if (!(o.flag & MEM_F_PE)) return -1;
+    return align_batch(idx, o, nullptr, b, read_id0, 1) ? 0 : -1;
+}
+
+size_t bwamem_hip_batch_pe_candidates(const bwamem_batch_t* b, int8_t* dir, int64_t* isize)
+{
+    if (!b) return 0;
+    std::vector<int8_t> d; std::vector<int64_t> is;
+    pe_candidates(b, d, is);
+    if (dir && isize && !d.empty()) { memcpy(dir, d.data(), d.size()); memcpy(isize, is.data(), is.size() * 8); }
+    return d.size();
+}
+
+void bwamem_hip_pestat(const mem_opt_t* opt, const int8_t* dir, const int64_t* isize, size_t n, mem_pestat_t* pes)
+{
+    MemOpt o; memcpy(&o, opt, sizeof o);
+    std::vector<int8_t> d(dir, dir + n); std::vector<int64_t> is(isize, isize + n);
+    host_pestat(o, d, is, (MemPestat*)pes);
+}
+
+int bwamem_hip_batch_pe_finish(bwaidx_t* idx, const mem_opt_t* opt, const mem_pestat_t* pes, bwamem_batch_t* b)
+{
+    if (!idx || !opt || !b || !pes) return -1;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (hipSetDevice(idx->device) != hipSuccess) return -1;
+    MemOpt o; memcpy(&o, opt, sizeof o);
+    return pe_finish(idx, o, (const MemPestat*)pes, b) ? 0 : -1;
+}
+
 size_t bwamem_hip_batch_result_bytes(const bwamem_batch_t* b) { return b->result_bytes; }
 
 int bwamem_hip_batch_download(bwamem_batch_t* b, void* dst)
@@ -1060,6 +1148,7 @@ void bwamem_hip_batch_free(bwamem_batch_t* b)
     if (!b) return;
     (void)hipSetDevice(b->idx->device);
     for (TileOut& t : b->tiles) if (t.d) (void)hipFree(t.d);
+    pe_call_free(b);
     b->d_raw.release(); b->d_seq.release(); b->d_off.release();
     delete b;
 }

@@ -69,6 +69,21 @@ bwamem_batch_t* bwamem_hip_batch_wrap_device(bwaidx_t* idx, const void* d_payloa
 /* run the whole hot path; results stay in HBM.  read_id0 = index of the first read within the
  * logical call (shards of one call must carry their global base index).  0 = ok. */
 int bwamem_hip_batch_align(bwaidx_t* idx, const mem_opt_t* opt, const mem_pestat_t* pes, bwamem_batch_t* b, int64_t read_id0);
+/* A paired-end call in two steps, for callers that shard ONE logical createAlignments call over several devices or
+ * ranks (caveat 2).  With inferred insert-size statistics (pes == NULL at jnibwa.c:214) upstream's
+ * mem_pestat is a reduction over all pairs of the call, between region finding and pairing; a shard must therefore
+ * stop after phase 1, hand out its per-pair (orientation, insert size) candidates, and finish with the statistics
+ * of the whole call:
+ *   _pe_begin       phase 1 (seeding .. regions) of this shard's reads; opt must carry MEM_F_PE (0x2 at offset 60)
+ *   _pe_candidates  n = pairs of the shard; dir[i] = orientation 0..3 or -1 (no candidate), isize[i] = insert size;
+ *                   dir == NULL: just returns n
+ *   bwamem_hip_pestat  upstream mem_pestat's reduction over candidates gathered from all shards (order-independent)
+ *   _pe_finish      phase 2 (mate rescue, pairing, records) with those statistics; then download as usual
+ * bwamem_hip_batch_align does the same in one call when the batch is the whole logical call. */
+int bwamem_hip_batch_pe_begin(bwaidx_t* idx, const mem_opt_t* opt, bwamem_batch_t* b, int64_t read_id0);
+size_t bwamem_hip_batch_pe_candidates(const bwamem_batch_t* b, int8_t* dir, int64_t* isize);
+void bwamem_hip_pestat(const mem_opt_t* opt, const int8_t* dir, const int64_t* isize, size_t n, mem_pestat_t* pes /* [4] */);
+int bwamem_hip_batch_pe_finish(bwaidx_t* idx, const mem_opt_t* opt, const mem_pestat_t* pes /* [4] */, bwamem_batch_t* b);
 size_t bwamem_hip_batch_result_bytes(const bwamem_batch_t* b);
 int bwamem_hip_batch_download(bwamem_batch_t* b, void* dst);
 void bwamem_hip_batch_free(bwamem_batch_t* b);

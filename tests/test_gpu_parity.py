@@ -223,6 +223,62 @@ def test_parity_pe_rescue_kernel_forms(hip_lib, oracle, small_genome):
     _parity_pe(hip_lib, oracle, img, _damaged_pairs(seqs, 300, 13, length=150, ins_mean=350))
 
 
+def test_pe_call_in_two_steps_for_sharded_callers(hip_lib, oracle, small_genome):
+    """bwamem_hip_batch_pe_begin / _candidates / bwamem_hip_pestat / _pe_finish (the exchange point of a call sharded over
+    several GPUs): two shards on this GPU, statistics reduced over both -> the single-call response"""
+    import ctypes, sys
+    sys.path.insert(0, B.PKG)
+    import sharding
+    seqs, img = small_genome
+    pairs = _damaged_pairs(seqs, 400, 21, ins_mean=280) + _damaged_pairs(seqs, 400, 22, ins_mean=420)
+    opts = B.set_opt(hip_lib.default_options(), flag=B.MEM_F_PE)
+    ho = oracle.open_index(img)
+    want = oracle.align_raw(ho, opts, B.pack_request(pairs))
+    oracle.destroy_index(ho)
+    d = hip_lib.dll
+    d.bwamem_hip_batch_upload.restype = ctypes.c_void_p
+    d.bwamem_hip_batch_upload.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    d.bwamem_hip_batch_pe_begin.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    d.bwamem_hip_batch_pe_candidates.restype = ctypes.c_size_t
+    d.bwamem_hip_batch_pe_candidates.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    d.bwamem_hip_pestat.restype = None
+    d.bwamem_hip_pestat.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    d.bwamem_hip_batch_pe_finish.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    d.bwamem_hip_batch_result_bytes.restype = ctypes.c_size_t
+    d.bwamem_hip_batch_result_bytes.argtypes = [ctypes.c_void_p]
+    d.bwamem_hip_batch_download.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    d.bwamem_hip_batch_free.argtypes = [ctypes.c_void_p]
+    h = hip_lib.open_index(img)
+    ob = ctypes.create_string_buffer(bytes(opts), 168)
+    shards, cand_d, cand_i = [], b"", b""
+    try:
+        for rank in range(2):
+            lo, hi = sharding.shard_range(len(pairs), rank, 2, paired=True)
+            req = B.pack_request(pairs[lo:hi])
+            batch = d.bwamem_hip_batch_upload(h, req, len(req))
+            assert batch and d.bwamem_hip_batch_pe_begin(h, ob, batch, lo) == 0
+            n = d.bwamem_hip_batch_pe_candidates(batch, None, None)
+            assert n == (hi - lo) // 2
+            db, ib = ctypes.create_string_buffer(n), ctypes.create_string_buffer(8 * n)
+            d.bwamem_hip_batch_pe_candidates(batch, db, ib)
+            cand_d += db.raw[:n]; cand_i += ib.raw[:8 * n]
+            shards.append(batch)
+        pes = ctypes.create_string_buffer(128)
+        d.bwamem_hip_pestat(ob, cand_d, cand_i, len(cand_d), pes)
+        got = b""
+        for batch in shards:
+            assert d.bwamem_hip_batch_pe_finish(h, ob, pes, batch) == 0
+            nb = d.bwamem_hip_batch_result_bytes(batch)
+            out = ctypes.create_string_buffer(max(nb, 1))
+            assert d.bwamem_hip_batch_download(batch, out) == 0
+            got += out.raw[:nb]
+        assert got == want
+    finally:
+        for batch in shards:
+            d.bwamem_hip_batch_free(batch)
+        hip_lib.destroy_index(h)
+
+
 def test_parity_pe_inferred_stats(hip_lib, oracle, small_genome):
     seqs, img = small_genome
     _parity_pe(hip_lib, oracle, img, _damaged_pairs(seqs, 1500, 5))
