@@ -340,14 +340,15 @@ static void debug_dump(Workspace& ws, const TileView& tv, int T)
 
 // Longest read the device path takes: the packed candidate format of the seeding kernel holds 17-bit positions, and the
 // general (LDS-row) form of the extension kernel keeps three int32 rows and the read of one workgroup in LDS
-// (13 bytes per base: about 12 500 bases with the 160 KB of a gfx950 CU).  Longer reads fail the call with a message.
+// (13 bytes per base: about 12 000 bases with the 160 KB of a gfx950 CU).  Longer reads fail the call with a message.
 static bool read_length_ok(const bwaidx_s* ix, int L)
 {
     if (L >= (1 << 17) - 1) { fprintf(stderr, "[bwamem_hip] reads of 131071 bases or more are not supported\n"); return false; }
     int lds = 0;
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, ix->device) != hipSuccess || lds <= 0) lds = 64 << 10;
-    if (extend_lds_bytes(L) > (size_t)lds) {
-        fprintf(stderr, "[bwamem_hip] a read of %d bases needs %zu bytes of LDS for the extension rows, the device offers %d: reads this long are not supported yet\n", L, extend_lds_bytes(L), lds);
+    const size_t need = extend_lds_bytes(L) + 6144 + 64;         // k_gcigar keeps the same rows plus a small traceback area (launch_gcigar)
+    if (need > (size_t)lds) {
+        fprintf(stderr, "[bwamem_hip] a read of %d bases needs %zu bytes of LDS for the extension rows, the device offers %d: reads this long are not supported yet\n", L, need, lds);
         return false;
     }
     return true;

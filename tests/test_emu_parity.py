@@ -103,3 +103,13 @@ def test_emu_mate_rescue_kernel_forms(emu, oracle, small_genome):
         pes = B.pack_pestat(ins - 150, ins + 150, float(ins), 30.0)
         assert emu.align_raw(h, opts, req, pes) == oracle.align_raw(ho, opts, req, pes)
         emu.destroy_index(h); oracle.destroy_index(ho)
+
+
+def test_emu_overlong_read_fails_the_call(emu, rota_img):
+    """a read whose extension rows would not fit a CU's LDS must make the call fail (NULL, message), never return records"""
+    h = emu.open_index(rota_img)
+    try:
+        assert emu.align_raw(h, emu.default_options(), B.pack_request([b"ACGT" * 5000])) is None
+        assert emu.align_raw(h, emu.default_options(), B.pack_request([b"ACGT" * 20])) is not None
+    finally:
+        emu.destroy_index(h)
