@@ -352,9 +352,9 @@ __global__ void __launch_bounds__(64) k_pe_rescue_sw(DevIndex ix, MemOpt opt, Ti
 
 // mem_sam_pe, first half (one lane per pair): mate rescue (step 3: upstream's sequence with the alignments precomputed),
 // primary marking, pairing and the mapping-quality decisions.
-// Regions whose CIGAR needs a banded global alignment are then listed as jobs for k_gcigar_lane / k_gcigar (any region of
-// either mate can end up in a record or an XA tag, so all of them are listed), and the record stage picks the results up:
-// a one-lane DP inside this kernel would stall the other 63 pairs of the wave.
+// Regions whose CIGAR needs a banded global alignment are then listed as jobs for k_gcigar_lane / k_gcigar (those the record
+// stage will use: records, XA entries, mate summaries), and the record stage picks the results up: a one-lane DP inside
+// this kernel would stall the other 63 pairs of the wave.
 __global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3, PeState* states,
                           const RescueJob* rjobs, const KswR* rres, const int32_t* job_first, const int32_t* job_num)
 {
@@ -435,13 +435,37 @@ __global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPe
     }
     PeState st; st.paired = paired; st.z0 = z[0]; st.z1 = z[1]; st.n_pri0 = n_pri[0]; st.n_pri1 = n_pri[1]; st.extra_flag = extra_flag; st.q_se0 = q_se[0]; st.q_se1 = q_se[1];
     states[pi] = st;
+    // Global-alignment jobs: the regions the record stage will turn into a record, an XA entry or a mate summary and whose
+    // CIGAR needs DP (same selection as k_pe_out, evaluated here with the final z / n_pri).  A region missed here would
+    // still come out right -- reg2aln then runs the one-lane DP itself -- so the list only has to be tight, not proven complete.
     DpJob* jobs = (DpJob*)tv.jobs;
     for (int i = 0; i < 2; ++i) {
         pv.n_regs[rd[i]] = n[i];
-        for (int j = 0; j < n[i]; ++j) {                        // regions whose CIGAR needs DP
+        int32_t *cnt = 0, *has_alt = 0;
+        if (!(opt.flag & MEM_F_ALL) && n[i] > 0) {
+            cnt = zb[i]; has_alt = zb[i] + n[i];
+            if (xa_prepare(opt, n[i], a[i], cnt, has_alt) == 0) cnt = has_alt = 0;
+        }
+        int alt_k = -1, which = -1;
+        if (paired) {
+            if (n_pri[i] < n[i]) {
+                const AlnReg* p = &a[i][n_pri[i]];
+                if (!(p->score < opt.T || p->secondary >= 0 || !p->is_alt)) alt_k = n_pri[i];
+            }
+        } else if (n[i]) {                                       // the region behind this end's mate summary
+            if (a[i][0].score >= opt.T) which = 0;
+            else if (n_pri[i] < n[i] && a[i][n_pri[i]].score >= opt.T) which = n_pri[i];
+        }
+        for (int j = 0; j < n[i]; ++j) {
             AlnReg* p = &a[i][j];
             p->pad_ = 0;
-            if (region_needs_dp(opt, *p)) {
+            const bool rec = paired ? (j == z[i] || j == alt_k) : (j == which || reg2sam_selects(opt, a[i], j));
+            bool xa = false;
+            if (cnt) {
+                const int pr = get_pri_idx(opt.XA_drop_ratio, a[i], j);
+                xa = pr >= 0 && (!paired || pr == z[i] || pr == alt_k) && !(cnt[pr] > opt.max_XA_hits_alt || (!has_alt[pr] && cnt[pr] > opt.max_XA_hits));
+            }
+            if ((rec || xa) && region_needs_dp(opt, *p)) {
                 int job = atomicAdd(tv.job_cnt, 1);
                 if (job < tv.job_cap) { DpJob jb; jb.read = rd[i]; jb.reg = j; jobs[job] = jb; p->pad_ = job + 1; }
                 else err |= ERR_JOB_CAP;
