@@ -144,6 +144,38 @@ def synth_reads(torch, dev, codes, contigs, n, length, seed, pos=None, rc=None):
     return payload
 
 
+def synth_long_reads(torch, dev, codes, contigs, n, length, seed):
+    """config 5 of BASELINE.json: ONT-style reads, 8 % substitutions, 3 % inserted and 3 % deleted bases
+    (single-base events), uniform position/strand.  Generated in chunks: the per-base index arithmetic is 8 bytes a base."""
+    g = torch.Generator(device=dev); g.manual_seed(seed ^ 0x0117)
+    total = codes.numel()
+    slack = int(length * 0.08) + 64
+    bounds = torch.tensor([0] + [l for _, l in contigs], device=dev).cumsum(0)
+    asc_tab = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    payload = torch.zeros((n, length + 1), dtype=torch.uint8, device=dev)
+    step = max(1, min(n, 200_000_000 // max(length, 1)))
+    for c0 in range(0, n, step):
+        m = min(step, n - c0)
+        pos = (torch.rand(m, generator=g, device=dev, dtype=torch.float64) * (total - length - slack)).long()
+        ci = torch.searchsorted(bounds, pos, right=True) - 1
+        pos = torch.where(pos + length + slack <= bounds[ci + 1], pos, torch.clamp(bounds[ci + 1] - length - slack, min=0))
+        ins = torch.rand(m, length, generator=g, device=dev) < 0.03                 # this output base is an inserted one
+        dele = torch.rand(m, length, generator=g, device=dev) < 0.03                # one reference base is skipped after this one
+        adv = torch.where(ins, torch.zeros((), dtype=torch.int64, device=dev), 1 + dele.long())
+        src = pos[:, None] + torch.cumsum(adv, 1) - adv                             # exclusive prefix: reference index of column j
+        src = torch.minimum(src, (pos + length + slack - 1)[:, None])
+        b = codes[src]
+        rnd = torch.randint(0, 4, (m, length), dtype=torch.uint8, generator=g, device=dev)
+        b = torch.where(ins, rnd, b)
+        sub = (torch.rand(m, length, generator=g, device=dev) < 0.08) & ~ins
+        b = torch.where(sub, (b + 1 + rnd % 3) % 4, b)
+        rc = torch.rand(m, generator=g, device=dev) < 0.5
+        b = torch.where(rc[:, None], torch.flip(3 - b, [1]), b)
+        payload[c0:c0 + m, :length] = asc_tab[b.long()]
+        del ins, dele, adv, src, b, rnd, sub
+    return payload
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +188,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=600_000, help="reads timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--paired", action="store_true", help="auxiliary measurement (BASELINE.json config 2): --reads is then the number of reads = 2 x pairs; "
                     "the library infers the insert-size statistics per call; metric/roofline fields are still reported for the seeding kernel")
+    ap.add_argument("--ont", action="store_true", help="auxiliary measurement (BASELINE.json config 5): ONT-style error model (8 %% substitutions, 3 %% insertions, "
+                    "3 %% deletions) for --read-len in the kilobases; use with a few thousand --reads")
     ap.add_argument("--pestat", default=None, help="with --paired: LOW,HIGH,AVG,STD of the FR insert size supplied by the caller (BwaMemAligner's "
                     "proper-pair statistics) instead of inferred per call; the call is then a single pass over the tiles")
     ap.add_argument("--keep-image", default=None, help="also copy the index image to this path (profiling helper)")
@@ -187,24 +221,32 @@ def main():
             print("[bench] %6.1fs %s" % (time.time() - t0, msg), file=sys.stderr, flush=True)
     codes, contigs = synth_genome(torch, dev, args.genome_bp, args.contigs, 0x5EED)
     note("synthetic genome ready")
-    import index_build_gpu as G
-    pieces = G.build_pieces(codes)
-    note("suffix array / BWT / occ / SA built on the device")
+    # every rank holds the same genome (it samples its own reads from it); the index is built once, by rank 0, and the
+    # image file is shared: one copy in the page cache of the node instead of one per rank
     tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
-    img = os.path.join(tmpdir, "bwamem_hip_bench_%d_%d.img" % (os.getpid(), rank))
-    G.write_image(img, pieces, contigs)
-    del pieces
-    torch.cuda.empty_cache()
+    img = os.path.join(tmpdir, "bwamem_hip_bench_%s.img" % (os.environ.get("MASTER_PORT", "p") + "_" + str(os.getppid()) if world > 1 else str(os.getpid())))
+    if rank == 0:
+        import index_build_gpu as G
+        pieces = G.build_pieces(codes)
+        note("suffix array / BWT / occ / SA built on the device")
+        G.write_image(img, pieces, contigs)
+        del pieces
+        torch.cuda.empty_cache()
+        note("index image written (%.2f GB)" % (os.path.getsize(img) / 1e9))
+    if dist is not None:
+        dist.barrier()
     t_index = time.time() - t0
-    note("index image written (%.2f GB)" % (os.path.getsize(img) / 1e9))
     idx = lib.jnibwa_openIndex(os.open(img, os.O_RDONLY))
     note("index resident in HBM")
     if not idx:
         raise SystemExit("openIndex failed")
+    if dist is not None:
+        dist.barrier()                       # every rank has the image mapped: rank 0 may unlink it at the end
 
     # ---- request resident in HBM (not timed)
     L, R = args.read_len, args.reads
-    payload = synth_pairs(torch, dev, codes, contigs, R // 2, L, 42 + rank) if args.paired else synth_reads(torch, dev, codes, contigs, R, L, 42 + rank)
+    payload = (synth_pairs(torch, dev, codes, contigs, R // 2, L, 42 + rank) if args.paired else
+               synth_long_reads(torch, dev, codes, contigs, R, L, 42 + rank) if args.ont else synth_reads(torch, dev, codes, contigs, R, L, 42 + rank))
     note("%d reads generated on the device" % R)
     del codes
     torch.cuda.empty_cache()
@@ -316,7 +358,7 @@ def main():
             "metric": "150bp reads aligned/sec vs GRCh38-scale reference (1/2/4/8 MI355X)", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32/int64", "data": "synthetic",
-            "config": {"workload": "%d x %dbp %s synthetic reads per GPU vs synthetic GRCh38-scale genome (%d bp, %d contigs, 5%% diverged repeats), full index in HBM" % (R, L, "paired-end (2 x %d pairs)" % (R // 2) if args.paired else "single-end", args.genome_bp, args.contigs),
+            "config": {"workload": "%d x %dbp %s synthetic reads per GPU vs synthetic GRCh38-scale genome (%d bp, %d contigs, 5%% diverged repeats), full index in HBM" % (R, L, "paired-end (2 x %d pairs)" % (R // 2) if args.paired else "single-end ONT-style (8 %% sub, 3 %% ins, 3 %% del)" if args.ont else "single-end", args.genome_bp, args.contigs),
                        "reads_per_gpu": R, "read_len": L, "genome_bp": args.genome_bp, "index_build_s": round(t_index, 1), "response_bytes": result_bytes,
                        "parallelism": "read-sharded x%d, no collectives" % world, "paired_end": bool(args.paired), "insert_size_statistics": ("supplied " + args.pestat) if (args.paired and args.pestat) else ("inferred per call" if args.paired else None)},
             "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
@@ -386,10 +428,11 @@ def main():
         print(json.dumps(out), flush=True)
     lib.bwamem_hip_batch_free(batch)
     lib.jnibwa_destroyIndex(idx)
-    try:
-        os.unlink(img)
-    except OSError:
-        pass
+    if rank == 0:                            # (the other ranks mapped it before the barrier above; an unlinked file lives until unmapped)
+        try:
+            os.unlink(img)
+        except OSError:
+            pass
     if dist is not None:
         dist.destroy_process_group()
 
