@@ -156,6 +156,8 @@ struct TileView {
     void* jobs;                   // DpJob[job_cap]
     int32_t job_cap;
     int32_t smem_groups;          // workgroups the smem_scratch spill area covers (upper bound for the k_seed grid)
+    int32_t* dp_rows;             // null: DP rows of k_extend / k_gcigar in LDS; else dp_rows_blocks slices of 3 x (max_len + 2) ints (very long reads)
+    int32_t dp_rows_blocks;
     int32_t debug;                // BWAMEM_HIP_DEBUGK: device-side progress prints (debugging aid)
     int32_t pad_;
 };

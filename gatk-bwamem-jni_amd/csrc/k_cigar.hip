@@ -319,18 +319,30 @@ __global__ void __launch_bounds__(64, 2) k_gcigar_lane(DevIndex ix, MemOpt opt, 
     outs[job] = o;
 }
 
-__global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView tv, const DpJob* jobs, DpOut* outs, uint32_t* cig_pool, int cig_cap,
+// HBM: as in k_extend -- rows of the general form in a slice of tv.dp_rows instead of LDS, a bounded grid walking the jobs
+template <bool HBM>
+__global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView tv, const DpJob* jobs, DpOut* outs, int n_jobs, uint32_t* cig_pool, int cig_cap,
                                                uint8_t* zpool, unsigned long long zpool_cap, unsigned long long* zpool_cur, int z_lds_cap)
 {
     HIP_DYNAMIC_SHARED(int32_t, smem)
-    const int job = blockIdx.x, lane = threadIdx.x;
-    if (outs[job].n_cigar >= 0) return;                                // done by k_gcigar_lane
+    const int lane = threadIdx.x;
+  for (int job = blockIdx.x; job < n_jobs; job += HBM ? (int)gridDim.x : n_jobs) {
+    __syncthreads();                                                   // (HBM) the previous job of this workgroup is done with the rows
+    if (outs[job].n_cigar >= 0) continue;                              // done by k_gcigar_lane
     const DpJob jb = jobs[job];
     const AlnReg ar = tv.regs[tv.seed_off[jb.read] + jb.reg];
     const uint8_t* query = tv.seq + tv.seq_off[jb.read];
     const int cap = tv.max_len + 2;
-    GLds L; L.eh_h = smem; L.eh_e = smem + cap; L.tmpM = smem + 2 * cap;
-    uint8_t* sq = (uint8_t*)(smem + 3 * cap);                          // the region's query bases, in alignment order
+    GLds L;
+    uint8_t* sq;                                                       // the region's query bases, in alignment order
+    if (HBM) {
+        int32_t* rows = tv.dp_rows + (size_t)blockIdx.x * 3 * (size_t)cap;
+        L.eh_h = rows; L.eh_e = rows + cap; L.tmpM = rows + 2 * cap;
+        sq = (uint8_t*)smem;
+    } else {
+        L.eh_h = smem; L.eh_e = smem + cap; L.tmpM = smem + 2 * cap;
+        sq = (uint8_t*)(smem + 3 * cap);
+    }
     uint8_t* z_lds = sq + ((cap + 15) & ~15);
     int err = 0;
     SeqAcc A; A.q = query + ar.qb; A.qlen = ar.qe - ar.qb; A.rev = ar.rb >= ix.l_pac; A.t0 = ar.rb; A.tlen = (int)(ar.re - ar.rb);
@@ -377,6 +389,7 @@ __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView
         outs[job] = o;
         if (err) atomicOr(tv.err, err);
     }
+  }
 }
 
 void launch_gcigar(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, int n_jobs, const void* jobs, void* outs, uint32_t* cig_pool, int cig_cap,
@@ -388,5 +401,10 @@ void launch_gcigar(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const 
     size_t cap = (size_t)tv.max_len + 2;
     size_t shmem = 3 * cap * sizeof(int32_t) + ((cap + 15) & ~(size_t)15) + (size_t)z_lds_cap + 64;
     hipLaunchKernelGGL(k_gcigar_lane<16>, dim3((n_jobs + 63) / 64), dim3(64), 0, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur);
-    hipLaunchKernelGGL(k_gcigar, dim3(n_jobs), dim3(64), shmem, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap);
+    if (tv.dp_rows) {
+        const int grid = n_jobs < tv.dp_rows_blocks ? n_jobs : tv.dp_rows_blocks;
+        hipLaunchKernelGGL(k_gcigar<true>, dim3(grid), dim3(64), ((cap + 15) & ~(size_t)15) + (size_t)z_lds_cap + 64, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap);
+        return;
+    }
+    hipLaunchKernelGGL(k_gcigar<false>, dim3(n_jobs), dim3(64), shmem, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap);
 }

@@ -356,16 +356,25 @@ struct U64Lt { __device__ bool operator()(uint64_t a, uint64_t b) const { return
 #ifndef K_EXTEND_MIN_WAVES
 #define K_EXTEND_MIN_WAVES 8
 #endif
-__global__ void __launch_bounds__(64, K_EXTEND_MIN_WAVES) k_extend(DevIndex ix, MemOpt opt, TileView tv)
+// HBM = false: one workgroup per read, the rows of the general DP form in LDS (every read up to ~12 000 bases).
+// HBM = true: reads whose rows do not fit a CU's LDS -- a bounded grid walks the reads and each workgroup keeps its rows in
+// its own slice of tv.dp_rows (global memory; only the read itself stays in LDS).  Same code, same results, slower rows.
+template <bool HBM>
+static __device__ __forceinline__ void extend_read(const DevIndex& ix, const MemOpt& opt, const TileView& tv, int32_t* smem, const int r, const int lane)
 {
-    HIP_DYNAMIC_SHARED(int32_t, smem)
-    const int r = blockIdx.x, lane = threadIdx.x;
     const int64_t s0 = tv.seed_off[r];
     const int l_query = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
     const int cap = tv.max_len + 2;
     ExtLds L;
-    L.eh_h = smem; L.eh_e = smem + cap; L.tmpM = smem + 2 * cap;
-    uint8_t* sq = (uint8_t*)(smem + 3 * cap);
+    uint8_t* sq;
+    if (HBM) {
+        int32_t* rows = tv.dp_rows + (size_t)blockIdx.x * 3 * (size_t)cap;
+        L.eh_h = rows; L.eh_e = rows + cap; L.tmpM = rows + 2 * cap;
+        sq = (uint8_t*)smem;
+    } else {
+        L.eh_h = smem; L.eh_e = smem + cap; L.tmpM = smem + 2 * cap;
+        sq = (uint8_t*)(smem + 3 * cap);
+    }
     L.query = sq;
     for (int j = lane; j < l_query; j += WAVE) sq[j] = tv.seq[tv.seq_off[r] + j];
     __syncthreads();
@@ -507,6 +516,17 @@ __global__ void __launch_bounds__(64, K_EXTEND_MIN_WAVES) k_extend(DevIndex ix, 
     }
 }
 
+template <bool HBM>
+__global__ void __launch_bounds__(64, K_EXTEND_MIN_WAVES) k_extend(DevIndex ix, MemOpt opt, TileView tv)
+{
+    HIP_DYNAMIC_SHARED(int32_t, smem)
+    if (!HBM) { extend_read<false>(ix, opt, tv, smem, blockIdx.x, threadIdx.x); return; }
+    for (int r = blockIdx.x; r < tv.n_reads; r += (int)gridDim.x) {
+        extend_read<true>(ix, opt, tv, smem, r, threadIdx.x);
+        __syncthreads();                                        // the next read reuses the rows and the staged query
+    }
+}
+
 // LDS of one k_extend workgroup for reads of up to max_len bases: the H, E and M rows of the general form + the read
 size_t extend_lds_bytes(int max_len)
 {
@@ -516,6 +536,12 @@ size_t extend_lds_bytes(int max_len)
 void launch_extend(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv)
 {
     if (tv.n_reads <= 0) return;
+    if (tv.dp_rows) {                                           // rows in global memory: tv.dp_rows_blocks slices of 3 x (max_len + 2) ints
+        const size_t cap = (size_t)tv.max_len + 2;
+        const int grid = tv.n_reads < tv.dp_rows_blocks ? tv.n_reads : tv.dp_rows_blocks;
+        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(64), (cap + 15) & ~(size_t)15, st, ix, opt, tv);
+        return;
+    }
     size_t shmem = extend_lds_bytes(tv.max_len);
-    hipLaunchKernelGGL(k_extend, dim3(tv.n_reads), dim3(64), shmem, st, ix, opt, tv);
+    hipLaunchKernelGGL(k_extend<false>, dim3(tv.n_reads), dim3(64), shmem, st, ix, opt, tv);
 }

@@ -61,12 +61,25 @@ enum KernelId { K_ENCODE, K_SEED, K_SA, K_CHAIN, K_EXTEND, K_POST, K_FINAL, K_PA
 
 struct Timed { KernelId id; hipEvent_t a, b; };
 
+// Do the DP rows of the general extension / global-alignment forms fit a CU's LDS for reads of L bases (13 bytes per base:
+// up to about 12 000 bases with 160 KB)?  If not they live in global memory (k_extend<true>, k_gcigar<true>).
+// BWAMEM_HIP_DP_ROWS=hbm forces that path (tests).
+static bool dp_rows_in_hbm(int L)
+{
+    static int lds = 0;
+    if (!lds) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || lds <= 0) lds = 64 << 10; }
+    const char* e = getenv("BWAMEM_HIP_DP_ROWS");
+    if (e && !strcmp(e, "hbm")) return true;
+    return extend_lds_bytes(L) + 6144 + 64 > (size_t)lds;
+}
+
 struct Workspace {
     int T = 0, L = 0, intv_cap = 0, smem_cap = 0, out_cap = 0;
     int64_t seed_cap = 0, post_per_read = 0;
     DevBuf intv, n_intv, smem, l_rep, n_seeds, seed_off, intv_seed_off;
     DevBuf seeds, seed_rid, cseeds, chains, chain_store, n_chains, bt_nodes, srt, regs, n_regs;
     DevBuf out, out_len, out_off, post, err, cnt;
+    DevBuf dp_rows; int dp_rows_blocks = 0;          // DP rows of k_extend / k_gcigar in global memory, only for reads too long for LDS rows
     DevBuf jobs, job_out, job_cig, job_cnt, zpool;   // single-end global-alignment jobs
     int job_cap = 0, job_cig_cap = 0; size_t zpool_cap = 0;
     int out_cap_hint = 512;                           // bytes per read of the output staging slots (grown on overflow, kept across tiles)
@@ -80,6 +93,12 @@ struct Workspace {
         size_t t = (size_t)T;
         if (with_seed && !(intv.ensure(t * intv_cap * sizeof(Intv)) && n_intv.ensure(t * 4) && smem.ensure(((t + 63) / 64 * 64) * 2 * smem_cap * 16)
             && l_rep.ensure(t * 4) && n_seeds.ensure(t * 4) && intv_seed_off.ensure(t * intv_cap * 4))) return false;
+        dp_rows_blocks = 0;
+        if (!with_seed && dp_rows_in_hbm(L)) {                                  // a bounded grid of workgroups, each with its own three rows (about 2 GB in all)
+            const size_t per_block = 3 * ((size_t)L + 2) * 4;
+            dp_rows_blocks = (int)std::min<size_t>(4096, std::max<size_t>(256, ((size_t)2 << 30) / per_block));
+            if (!dp_rows.ensure((size_t)dp_rows_blocks * per_block)) return false;
+        }
         return seed_off.ensure((t + 1) * 8)
             && n_chains.ensure(t * 4) && n_regs.ensure(t * 4) && out.ensure(t * out_cap) && out_len.ensure(t * 4)
             && out_off.ensure((t + 1) * 8) && post.ensure(t * (size_t)post_per_read) && err.ensure(64) && cnt.ensure(sizeof(DevCounters));
@@ -98,7 +117,7 @@ struct Workspace {
     }
     void release() {
         DevBuf* all[] = { &intv, &n_intv, &smem, &l_rep, &n_seeds, &seed_off, &intv_seed_off, &seeds, &seed_rid, &cseeds, &chains,
-                          &chain_store, &n_chains, &bt_nodes, &srt, &regs, &n_regs, &out, &out_len, &out_off, &post, &err, &cnt,
+                          &chain_store, &n_chains, &bt_nodes, &srt, &regs, &n_regs, &out, &out_len, &out_off, &post, &err, &cnt, &dp_rows,
                           &jobs, &job_out, &job_cig, &job_cnt, &zpool, &pe_dir, &pe_is, &pe_caps, &pe_reg_off2, &pe_regs2, &pe_ints2, &pe_vpool, &pe_scratch, &pe_states,
                           &pe_rescue[0], &pe_rescue[1], &pe_rescue[2] };
         for (DevBuf* b : all) b->release();
@@ -115,6 +134,7 @@ struct Workspace {
         tv.out_cap = out_cap; tv.out = out.as<uint8_t>(); tv.out_len = out_len.as<int32_t>(); tv.out_off = out_off.as<int64_t>();
         tv.post_scratch = post.as<uint8_t>(); tv.post_scratch_per_read = post_per_read;
         tv.err = err.as<int32_t>(); tv.cnt = cnt.as<DevCounters>();
+        tv.dp_rows = dp_rows_blocks ? dp_rows.as<int32_t>() : nullptr; tv.dp_rows_blocks = dp_rows_blocks;
         tv.job_cnt = job_cnt.as<int32_t>(); tv.jobs = jobs.p; tv.job_cap = job_cap;
         tv.smem_groups = (T + 63) / 64;
         { const char* e = getenv("BWAMEM_HIP_DEBUGK"); tv.debug = e ? atoi(e) : 0; }
@@ -338,19 +358,12 @@ static void debug_dump(Workspace& ws, const TileView& tv, int T)
     fflush(stderr);
 }
 
-// Longest read the device path takes: the packed candidate format of the seeding kernel holds 17-bit positions, and the
-// general (LDS-row) form of the extension kernel keeps three int32 rows and the read of one workgroup in LDS
-// (13 bytes per base: about 12 000 bases with the 160 KB of a gfx950 CU).  Longer reads fail the call with a message.
+// Longest read the device path takes: the packed candidate format of the seeding kernel holds 17-bit positions.  (Reads
+// beyond about 12 000 bases keep their DP rows in global memory instead of LDS: dp_rows_in_hbm.)
 static bool read_length_ok(const bwaidx_s* ix, int L)
 {
+    (void)ix;
     if (L >= (1 << 17) - 1) { fprintf(stderr, "[bwamem_hip] reads of 131071 bases or more are not supported\n"); return false; }
-    int lds = 0;
-    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, ix->device) != hipSuccess || lds <= 0) lds = 64 << 10;
-    const size_t need = extend_lds_bytes(L) + 6144 + 64;         // k_gcigar keeps the same rows plus a small traceback area (launch_gcigar)
-    if (need > (size_t)lds) {
-        fprintf(stderr, "[bwamem_hip] a read of %d bases needs %zu bytes of LDS for the extension rows, the device offers %d: reads this long are not supported yet\n", L, need, lds);
-        return false;
-    }
     return true;
 }
 

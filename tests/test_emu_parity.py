@@ -105,11 +105,12 @@ def test_emu_mate_rescue_kernel_forms(emu, oracle, small_genome):
         emu.destroy_index(h); oracle.destroy_index(ho)
 
 
-def test_emu_overlong_read_fails_the_call(emu, rota_img):
-    """a read whose extension rows would not fit a CU's LDS must make the call fail (NULL, message), never return records"""
-    h = emu.open_index(rota_img)
-    try:
-        assert emu.align_raw(h, emu.default_options(), B.pack_request([b"ACGT" * 5000])) is None
-        assert emu.align_raw(h, emu.default_options(), B.pack_request([b"ACGT" * 20])) is not None
-    finally:
-        emu.destroy_index(h)
+def test_emu_dp_rows_in_global_memory(emu, oracle, rota_img, small_genome, monkeypatch):
+    """reads too long for LDS rows (beyond ~12 000 bases) run k_extend / k_gcigar with their rows in global memory; the same
+    path forced on ordinary reads must give the same bytes, and a 20 kb read must go through"""
+    seqs, img = small_genome
+    reads = B.simulate_reads(seqs, 12, length=150, seed=9, sub=0.03, indel=0.01) + B.simulate_reads(seqs, 4, length=400, seed=10, sub=0.05, indel=0.02)
+    monkeypatch.setenv("BWAMEM_HIP_DP_ROWS", "hbm")
+    _cmp(emu, oracle, img, reads)
+    monkeypatch.delenv("BWAMEM_HIP_DP_ROWS")
+    _cmp(emu, oracle, rota_img, [b"ACGT" * 5000, b"ACGT" * 20])

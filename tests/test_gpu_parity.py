@@ -309,3 +309,15 @@ def test_parity_long_reads(hip_lib, oracle, medium_genome):
     reads += B.simulate_reads(seqs, 40, length=3000, seed=6, sub=0.08, indel=0.03, random_frac=0.0)
     reads += B.simulate_reads(seqs, 6, length=10000, seed=7, sub=0.08, indel=0.06, random_frac=0.0)
     _parity(hip_lib, oracle, img, reads)
+
+
+def test_parity_reads_beyond_lds_rows(hip_lib, oracle, medium_genome, small_genome, monkeypatch):
+    """beyond ~12 000 bases the DP rows of k_extend / k_gcigar live in global memory (k_extend<true>, k_gcigar<true>)"""
+    seqs, img = medium_genome
+    reads = B.simulate_reads(seqs, 3, length=16000, seed=8, sub=0.08, indel=0.06, random_frac=0.0)
+    reads += B.simulate_reads(seqs, 2, length=40000, seed=9, sub=0.05, indel=0.04, random_frac=0.0)
+    reads += B.simulate_reads(seqs, 20, length=150, seed=10)
+    _parity(hip_lib, oracle, img, reads)
+    seqs, img = small_genome                           # the same kernels forced on ordinary reads, many per workgroup
+    monkeypatch.setenv("BWAMEM_HIP_DP_ROWS", "hbm")
+    _parity(hip_lib, oracle, img, B.simulate_reads(seqs, 3000, length=150, seed=11, sub=0.03, indel=0.005))
