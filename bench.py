@@ -423,6 +423,17 @@ def main():
         out["jni_call_host_to_host"] = {"reads": S, "reads_per_s": S / tj if tj > 0 else None, "note": "jnibwa_createAlignments, PCIe both ways included; never `value`"}
         if tail is not None:
             out["parity_sample_tail"] = tail
+        if os.environ.get("BENCH_JNI_FULL"):     # the whole batch through the drop-in entry point (host request in, host response out), twice: first call sizes the workspaces
+            full = struct.pack("<i", R) + payload.cpu().numpy().tobytes()
+            fb = ctypes.create_string_buffer(full, len(full)); del full
+            ts = []
+            for _ in range(2):
+                fz = ctypes.c_size_t(); t1 = time.time()
+                fp = lib.jnibwa_createAlignments(idx, opts, pes, fb, ctypes.byref(fz))
+                ts.append(time.time() - t1)
+                if fp:
+                    lib.jnibwa_free(fp)
+            out["jni_call_host_to_host_full_batch"] = {"reads": R, "seconds": [round(t, 4) for t in ts], "reads_per_s": R / ts[-1], "response_bytes": fz.value}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

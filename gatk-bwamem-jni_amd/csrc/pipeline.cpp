@@ -1063,28 +1063,35 @@ void* jnibwa_getRefContigNames(bwaidx_t* pIdx, size_t* pBufSize)
     return bufMem;
 }
 
+// the request's strings (payload = pSeq + 4) with their offsets already known: device copies of both
+static bwamem_batch_s* batch_from_offsets(bwaidx_t* idx, const char* payload, uint32_t n_reads, std::vector<int64_t>&& off)
+{
+    if (hipSetDevice(idx->device) != hipSuccess) return 0;
+    bwamem_batch_s* b = new bwamem_batch_s();
+    b->idx = idx; b->n_reads = n_reads;
+    b->h_off = std::move(off);
+    b->n_bytes = (size_t)b->h_off[n_reads];
+    bool ok = b->d_raw.ensure(b->n_bytes + 64) && b->d_seq.ensure(b->n_bytes + 64) && b->d_off.ensure(((size_t)n_reads + 1) * 8);
+    ok = ok && hipMemcpy(b->d_raw.p, payload, b->n_bytes, hipMemcpyHostToDevice) == hipSuccess
+            && hipMemcpy(b->d_off.p, b->h_off.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { fprintf(stderr, "[bwamem_hip] request upload failed\n"); bwamem_hip_batch_free(b); return 0; }
+    return b;
+}
+
 bwamem_batch_t* bwamem_hip_batch_upload(bwaidx_t* idx, const char* pSeq, size_t nBytes)
 {
     if (!idx || !pSeq || nBytes < 4) return 0;
-    if (hipSetDevice(idx->device) != hipSuccess) return 0;
-    bwamem_batch_s* b = new bwamem_batch_s();
-    b->idx = idx;
-    memcpy(&b->n_reads, pSeq, 4);
+    uint32_t n_reads; memcpy(&n_reads, pSeq, 4);
     const char* p = pSeq + 4; const char* end = pSeq + nBytes;
-    b->h_off.resize((size_t)b->n_reads + 1);
-    for (uint32_t i = 0; i < b->n_reads; ++i) {          // jnibwa.c:204-212 (strlen walk)
-        b->h_off[i] = p - (pSeq + 4);
+    std::vector<int64_t> off((size_t)n_reads + 1);
+    for (uint32_t i = 0; i < n_reads; ++i) {              // jnibwa.c:204-212 (strlen walk)
+        off[i] = p - (pSeq + 4);
         const char* z = (const char*)memchr(p, 0, (size_t)(end - p));
-        if (!z) { fprintf(stderr, "[bwamem_hip] request buffer ends inside read %u\n", i); delete b; return 0; }
+        if (!z) { fprintf(stderr, "[bwamem_hip] request buffer ends inside read %u\n", i); return 0; }
         p = z + 1;
     }
-    b->h_off[b->n_reads] = p - (pSeq + 4);
-    b->n_bytes = (size_t)b->h_off[b->n_reads];
-    bool ok = b->d_raw.ensure(b->n_bytes + 64) && b->d_seq.ensure(b->n_bytes + 64) && b->d_off.ensure(((size_t)b->n_reads + 1) * 8);
-    ok = ok && hipMemcpy(b->d_raw.p, pSeq + 4, b->n_bytes, hipMemcpyHostToDevice) == hipSuccess
-            && hipMemcpy(b->d_off.p, b->h_off.data(), ((size_t)b->n_reads + 1) * 8, hipMemcpyHostToDevice) == hipSuccess;
-    if (!ok) { fprintf(stderr, "[bwamem_hip] request upload failed\n"); bwamem_hip_batch_free(b); return 0; }
-    return b;
+    off[n_reads] = p - (pSeq + 4);
+    return batch_from_offsets(idx, pSeq + 4, n_reads, std::move(off));
 }
 
 bwamem_batch_t* bwamem_hip_batch_wrap_device(bwaidx_t* idx, const void* d_payload, size_t nBytes, uint32_t nReads, const int64_t* h_offsets)
@@ -1171,11 +1178,12 @@ void* jnibwa_createAlignments(bwaidx_t* pIdx, mem_opt_t* pOpts, mem_pestat_t* pe
 {
     if (pBufSize) *pBufSize = 0;
     if (!pIdx || !pOpts || !pSeq) return 0;
-    // total request size: walk the NUL-terminated strings exactly as the reference does
+    // the request carries no length: walk the NUL-terminated strings exactly as the reference does (jnibwa.c:204-212),
+    // once, keeping the offsets
     uint32_t n; memcpy(&n, pSeq, 4);
-    size_t nBytes = 4;
-    { const char* p = pSeq + 4; for (uint32_t i = 0; i < n; ++i) p += strlen(p) + 1; nBytes = (size_t)(p - pSeq); }
-    bwamem_batch_t* b = bwamem_hip_batch_upload(pIdx, pSeq, nBytes);
+    std::vector<int64_t> off((size_t)n + 1);
+    { const char* p = pSeq + 4; for (uint32_t i = 0; i < n; ++i) { off[i] = p - (pSeq + 4); p += strlen(p) + 1; } off[n] = p - (pSeq + 4); }
+    bwamem_batch_t* b = batch_from_offsets(pIdx, pSeq + 4, n, std::move(off));
     if (!b) return 0;
     void* res = 0;
     if (bwamem_hip_batch_align(pIdx, pOpts, peStats, b, 0) == 0) {
