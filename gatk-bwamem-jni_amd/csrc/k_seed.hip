@@ -72,28 +72,42 @@ DEV void extend_sm(const DevIndex& ix, uint64_t x0, uint64_t x1, uint64_t size, 
 // text < 2^37 symbols, reads < 2^17 bases.
 struct CandStack {
     uint32_t *v0, *v1, *v2;     // LDS planes, already offset by the lane
+    uint16_t* v2n;              // the third plane as 16-bit entries when `narrow` (same base address as v2 would have)
     uint4* spill;               // [spill_cap][64], already offset by the lane
     int K, spill_cap;
+    bool narrow;                // text < 2^35 symbols and reads < 1023 bases: {x0 hi:3, size hi:3, end:10} fit 16 bits -- 2 KB less LDS per wave, one more wave per SIMD pair
     static __device__ uint32_t pack2(uint64_t x0, uint64_t size, int end) { return (uint32_t)(x0 >> 32) | (uint32_t)(size >> 32) << 5 | (uint32_t)end << 10; }
+    // third word of ring slot e, in pack2's layout
+    __device__ uint32_t hi_get(int e) const {
+        const int s = (e & (K - 1)) * 64;
+        if (!narrow) return v2[s];
+        const uint32_t h = v2n[s];
+        return (h & 7u) | (h >> 3 & 7u) << 5 | (h >> 6) << 10;
+    }
+    __device__ void hi_put(int e, uint32_t w2) {
+        const int s = (e & (K - 1)) * 64;
+        if (!narrow) v2[s] = w2;
+        else v2n[s] = (uint16_t)((w2 & 7u) | (w2 >> 5 & 7u) << 3 | (w2 >> 10) << 6);
+    }
     // forward phase: entry e becomes the new top (height e + 1); the entry leaving the ring goes to the global area
     __device__ bool push(int e, uint64_t x0, uint64_t size, int end) {
         const int s = (e & (K - 1)) * 64;
         if (e >= K) {
             if (e - K >= spill_cap) return false;
-            uint4 t; t.x = v0[s]; t.y = v1[s]; t.z = v2[s]; t.w = 0;
+            uint4 t; t.x = v0[s]; t.y = v1[s]; t.z = hi_get(e); t.w = 0;
             spill[(size_t)(e - K) * 64] = t;
         }
-        v0[s] = (uint32_t)x0; v1[s] = (uint32_t)size; v2[s] = pack2(x0, size, end);
+        v0[s] = (uint32_t)x0; v1[s] = (uint32_t)size; hi_put(e, pack2(x0, size, end));
         return true;
     }
     // backward phase, stack height n fixed: entries n-K .. n-1 are in the ring
     __device__ void put(int e, int n, uint64_t x0, uint64_t size, int end) {
-        if (e >= n - K) { const int s = (e & (K - 1)) * 64; v0[s] = (uint32_t)x0; v1[s] = (uint32_t)size; v2[s] = pack2(x0, size, end); }
+        if (e >= n - K) { const int s = (e & (K - 1)) * 64; v0[s] = (uint32_t)x0; v1[s] = (uint32_t)size; hi_put(e, pack2(x0, size, end)); }
         else { uint4 t; t.x = (uint32_t)x0; t.y = (uint32_t)size; t.z = pack2(x0, size, end); t.w = 0; spill[(size_t)e * 64] = t; }
     }
     __device__ void get(int e, int n, uint64_t& x0, uint64_t& size, int& end) const {
         uint32_t a, b, w2;
-        if (e >= n - K) { const int s = (e & (K - 1)) * 64; a = v0[s]; b = v1[s]; w2 = v2[s]; }
+        if (e >= n - K) { const int s = (e & (K - 1)) * 64; a = v0[s]; b = v1[s]; w2 = hi_get(e); }
         else { const uint4 t = spill[(size_t)e * 64]; a = t.x; b = t.y; w2 = t.z; }
         x0 = (uint64_t)(w2 & 31) << 32 | a; size = (uint64_t)(w2 >> 5 & 31) << 32 | b; end = (int)(w2 >> 10);
     }
@@ -132,14 +146,16 @@ enum { S_IDLE = 0, S_NEXT = 1, S_FWD = 2, S_BWD = 3, S_P3 = 4 };
 #define SEED_EL_CAP 4
 
 template <bool LDSQ>
-__global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView tv, int K, int refill_min)
+__global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView tv, int K, int refill_min, int narrow)
 {
     HIP_DYNAMIC_SHARED(uint32_t, lds)
     const int lane = threadIdx.x;
     CandStack V;
+    V.narrow = narrow != 0;
     V.v0 = lds + lane; V.v1 = V.v0 + K * 64; V.v2 = V.v1 + K * 64; V.K = K;
+    V.v2n = (uint16_t*)(lds + 2 * K * 64) + lane;
     V.spill = (uint4*)tv.smem_scratch + (size_t)blockIdx.x * tv.smem_cap * 64 + lane; V.spill_cap = tv.smem_cap;
-    uint32_t* el = lds + 3 * K * 64 + lane;              // [SEED_EL_CAP][64 lanes]: pass-1 matches that pass 2 re-seeds (mid:17 | size:15)
+    uint32_t* el = lds + (narrow ? 5 * K * 32 : 3 * K * 64) + lane;   // [SEED_EL_CAP][64 lanes]: pass-1 matches that pass 2 re-seeds (mid:17 | size:15)
     uint32_t* sq = el + SEED_EL_CAP * 64;                // [word][64 lanes]: the lanes' current reads, 8 base codes per word
     unsigned int* work = (unsigned int*)(tv.err + 8);    // next unclaimed read of the tile
     const int min_seed_len = opt.min_seed_len;
@@ -499,13 +515,15 @@ void launch_seed(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const Ti
     while (K & (K - 1)) K &= K - 1;                                  // the candidate ring needs a power of two
     const size_t qbytes = (size_t)64 * 4 * (((size_t)tv.max_len + 7) / 8);
     const bool ldsq = qbytes <= 24576;
-    const size_t lds = (size_t)3 * K * 64 * 4 + (size_t)SEED_EL_CAP * 64 * 4 + (ldsq ? qbytes : 0) + 16;
+    int narrow = ix.seq_len < (1ull << 35) && tv.max_len < 1023;
+    { const char* e = getenv("BWAMEM_HIP_SEED_NARROW"); if (e) narrow = narrow && atoi(e) != 0; }
+    const size_t lds = (size_t)(narrow ? 5 * K * 32 : 3 * K * 64) * 4 + (size_t)SEED_EL_CAP * 64 * 4 + (ldsq ? qbytes : 0) + 16;
     if (!wpc) { wpc = (int)((size_t)(160 * 1024) / ((lds + 1023) & ~(size_t)1023)); wpc = wpc < 1 ? 1 : wpc > 16 ? 16 : wpc; }
     const int groups = (tv.n_reads + 63) / 64;
     int grid = groups < n_cu * wpc ? groups : n_cu * wpc;
     if (tv.smem_groups > 0 && grid > tv.smem_groups) grid = tv.smem_groups;
-    if (ldsq) hipLaunchKernelGGL(k_seed<true>, dim3(grid), dim3(64), lds, st, ix, opt, tv, K, refill_min);
-    else hipLaunchKernelGGL(k_seed<false>, dim3(grid), dim3(64), lds, st, ix, opt, tv, K, refill_min);
+    if (ldsq) hipLaunchKernelGGL(k_seed<true>, dim3(grid), dim3(64), lds, st, ix, opt, tv, K, refill_min, narrow);
+    else hipLaunchKernelGGL(k_seed<false>, dim3(grid), dim3(64), lds, st, ix, opt, tv, K, refill_min, narrow);
     hipLaunchKernelGGL(k_seed_fin, dim3((tv.n_reads + 255) / 256), dim3(256), 0, st, opt, tv);
 }
 void launch_scan(hipStream_t st, const int32_t* in, int64_t* out, int n)
