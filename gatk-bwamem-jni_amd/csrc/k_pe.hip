@@ -479,7 +479,7 @@ __global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPe
 // nothing at this stage writes to the regions, so a mate only needs the other's position summary (a `light` reg2aln of
 // the other mate's chosen region, recomputed here rather than exchanged) and the two records are otherwise independent --
 // twice the waves and half the dependent chain of a lane-per-pair layout, which is what this latency-bound stage wants
-__global__ void k_pe_out(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3, const PeState* states, JobView jvv)
+__global__ void __launch_bounds__(64, 6) k_pe_out(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3, const PeState* states, JobView jvv)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= (tv.n_reads & ~1)) return;

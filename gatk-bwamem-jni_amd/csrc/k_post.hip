@@ -77,7 +77,9 @@ __global__ void k_final_prep(DevIndex ix, MemOpt opt, TileView tv)
 }
 
 // step 3 (after k_gcigar): mem_reg2sam record selection and the reference's fmt_BAMish record writer
-__global__ void k_final_se(DevIndex ix, MemOpt opt, TileView tv, JobView jv)
+// (64, 6): a tile's 6 144 waves are six per SIMD; with the default register budget only four would be resident, and this stage
+// waits on dependent loads most of the time
+__global__ void __launch_bounds__(64, 6) k_final_se(DevIndex ix, MemOpt opt, TileView tv, JobView jv)
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= tv.n_reads) return;
