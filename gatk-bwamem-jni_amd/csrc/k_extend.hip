@@ -371,9 +371,10 @@ static __device__ __forceinline__ void extend_read(const DevIndex& ix, const Mem
         int32_t* rows = tv.dp_rows + (size_t)blockIdx.x * 3 * (size_t)cap;
         L.eh_h = rows; L.eh_e = rows + cap; L.tmpM = rows + 2 * cap;
         sq = (uint8_t*)smem;
-    } else {
-        L.eh_h = smem; L.eh_e = smem + cap; L.tmpM = smem + 2 * cap;
-        sq = (uint8_t*)(smem + 3 * cap);
+    } else {                                                    // the read first: tiles of short reads (register form only) allocate nothing else
+        sq = (uint8_t*)smem;
+        int32_t* rows = smem + (((size_t)cap + 15) & ~(size_t)15) / 4;
+        L.eh_h = rows; L.eh_e = rows + cap; L.tmpM = rows + 2 * cap;
     }
     L.query = sq;
     for (int j = lane; j < l_query; j += WAVE) sq[j] = tv.seq[tv.seq_off[r] + j];
@@ -542,6 +543,8 @@ void launch_extend(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const 
         hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(64), (cap + 15) & ~(size_t)15, st, ix, opt, tv);
         return;
     }
-    size_t shmem = extend_lds_bytes(tv.max_len);
+    // every query of a tile whose reads are at most 3 * 64 - 1 bases long takes the register form: no rows in LDS, only the
+    // read -- which matters for overlap, because k_seed fills the CUs' LDS and a workgroup that asks for 2 KB finds no room
+    size_t shmem = tv.max_len + 1 <= 3 * WAVE ? (((size_t)tv.max_len + 2 + 15) & ~(size_t)15) : extend_lds_bytes(tv.max_len);
     hipLaunchKernelGGL(k_extend<false>, dim3(tv.n_reads), dim3(64), shmem, st, ix, opt, tv);
 }
