@@ -202,12 +202,20 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend -- exercises the N > 1 code path (shared image, barriers,
+    # max-over-ranks timing) on a one-GPU box; not a measurement
+    rehearsal = bool(os.environ.get("BENCH_REHEARSAL"))
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     lib = load_lib()
     lib.bwamem_hip_set_device(local)
 
@@ -293,7 +301,7 @@ def main():
     barrier()
     elapsed = time.time() - t1
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st_timed = Stats(); lib.bwamem_hip_stats_get(ctypes.byref(st_timed))
