@@ -302,6 +302,30 @@ def test_pe_multi_tile(hip_lib, oracle, small_genome, monkeypatch):
     assert _parity_pe(hip_lib, oracle, img, pairs) == whole
 
 
+def test_concurrent_calls_on_one_index(hip_lib, oracle, small_genome):
+    """BwaMemIndex is shared by many Java threads, each with its own BwaMemAligner (BwaMemIndex.java:16-27): concurrent
+    jnibwa_createAlignments calls on one index must each return their own correct response (the library serialises them per
+    device)"""
+    import threading
+    seqs, img = small_genome
+    batches = [B.simulate_reads(seqs, 400 + 50 * k, length=150, seed=100 + k, sub=0.02, indel=0.003) for k in range(6)]
+    ho = oracle.open_index(img)
+    want = [oracle.align_raw(ho, oracle.default_options(), B.pack_request(b)) for b in batches]
+    oracle.destroy_index(ho)
+    h = hip_lib.open_index(img)
+    got = [None] * len(batches)
+    def work(k):
+        for _ in range(3):
+            got[k] = hip_lib.align_raw(h, hip_lib.default_options(), B.pack_request(batches[k]))
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(batches))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    hip_lib.destroy_index(h)
+    assert got == want
+
+
 def test_parity_long_reads(hip_lib, oracle, medium_genome):
     """config-5 style reads: seed re-scoring (row a10), wide bands, long chains, big global alignments"""
     seqs, img = medium_genome
