@@ -179,7 +179,7 @@ DEV int chain_weight(const Chain& c, const Seed* seeds)
 
 struct ChainWLt { __device__ bool operator()(const Chain& a, const Chain& b) const { return a.w > b.w; } };
 
-__global__ void k_chain(DevIndex ix, MemOpt opt, TileView tv, Chain* chain_store)
+__global__ void __launch_bounds__(64, 8) k_chain(DevIndex ix, MemOpt opt, TileView tv, Chain* chain_store)
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= tv.n_reads) return;

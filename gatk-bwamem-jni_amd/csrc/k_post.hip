@@ -10,7 +10,7 @@
 #include "kernels.h"
 #include "post_common.h"
 
-__global__ void k_post1(DevIndex ix, MemOpt opt, TileView tv)
+__global__ void __launch_bounds__(64, 6) k_post1(DevIndex ix, MemOpt opt, TileView tv)
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= tv.n_reads) return;
@@ -41,7 +41,7 @@ __global__ void k_post1(DevIndex ix, MemOpt opt, TileView tv)
 
 // ------------------------------------------------------------------ single-end finalisation
 // step 1: primary marking, and a job for every region whose record (or XA entry) needs a banded global alignment
-__global__ void k_final_prep(DevIndex ix, MemOpt opt, TileView tv)
+__global__ void __launch_bounds__(64, 6) k_final_prep(DevIndex ix, MemOpt opt, TileView tv)
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= tv.n_reads) return;
