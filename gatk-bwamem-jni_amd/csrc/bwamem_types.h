@@ -46,6 +46,11 @@ static_assert(sizeof(MemOpt) == 168, "mem_opt_t ABI (BwaMemAligner.java:137)");
 struct MemPestat { int low, high; int failed; double avg, std; };
 static_assert(sizeof(MemPestat) == 32, "mem_pestat_t ABI");
 
+// mem_pair's insert-size score term log(2 erfc(|dist - avg| / std / sqrt 2)) for every integer distance an orientation
+// admits, computed by the host's glibc (pipeline.cpp: build_pair_tab): t[off[d] + dist - lo[d]] for dist in
+// [lo[d], lo[d] + n[d]); a distance within [low, high] but outside that range has erfc == 0 exactly, i.e. the term is -inf
+struct PairTab { const double* t; int64_t lo[4]; int32_t n[4], off[4]; };
+
 enum {
     MEM_F_PE = 0x2, MEM_F_NOPAIRING = 0x4, MEM_F_ALL = 0x8, MEM_F_NO_MULTI = 0x10,
     MEM_F_NO_RESCUE = 0x20, MEM_F_PRIMARY5 = 0x800

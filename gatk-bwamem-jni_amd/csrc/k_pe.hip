@@ -153,7 +153,11 @@ DEV int matesw(const DevIndex& ix, const MemOpt& opt, PostScratch& S, SwScratch&
 struct Pair64 { uint64_t x, y; };
 struct Pair64Lt { __device__ bool operator()(const Pair64& a, const Pair64& b) const { return a.x < b.x || (a.x == b.x && a.y < b.y); } };
 
-DEV int mem_pair(const DevIndex& ix, const MemOpt& opt, const MemPestat* pes, const AlnReg* a0, const AlnReg* a1, int id,
+// The insert-size term of a pair's score, log(2 erfc(|dist - avg| / std / sqrt 2)), is a libm value: it comes from a
+// host-built (glibc) table over the integer distances an orientation admits (PairTab, pipeline.cpp: build_pair_tab), so
+// that the truncation below sees the very doubles the reference's host code sees.  Distances outside the
+// table are those for which glibc's erfc is exactly 0.
+DEV int mem_pair(const DevIndex& ix, const MemOpt& opt, const MemPestat* pes, const PairTab& pt, const AlnReg* a0, const AlnReg* a1, int id,
                  int* sub, int* n_sub, int z[2], const int n_pri[2], Pair64* v, Pair64* u, int cap_u, int& err)
 {
     const int64_t l_pac = ix.l_pac;
@@ -180,13 +184,16 @@ DEV int mem_pair(const DevIndex& ix, const MemOpt& opt, const MemPestat* pes, co
             for (k = y[which]; k >= 0; --k) {
                 int64_t dist;
                 int q;
-                double ns;
+                double lg;
                 if ((int)(v[k].y & 3) != which) continue;
                 dist = (int64_t)v[i].x - (int64_t)v[k].x;
                 if (dist > pes[dir].high) break;
                 if (dist < pes[dir].low) continue;
-                ns = (dist - pes[dir].avg) / pes[dir].std;
-                q = (int)((v[i].y >> 32) + (v[k].y >> 32) + .721 * log(2. * erfc(fabs(ns) * 0.70710678118654752440)) * opt.a + .499);
+                {
+                    const int64_t o = dist - pt.lo[dir];
+                    lg = o >= 0 && o < (int64_t)pt.n[dir] ? pt.t[pt.off[dir] + o] : -__builtin_inf();
+                }
+                q = (int)((v[i].y >> 32) + (v[k].y >> 32) + .721 * lg * opt.a + .499);
                 if (q < 0) q = 0;
                 if (nu >= cap_u) { err |= ERR_SCRATCH; return 0; }
                 Pair64* p = &u[nu++];
@@ -226,6 +233,7 @@ struct PeView {
     int64_t scratch_per_pair;
     void* vpool;              // Pair64 per region slot (indexed by reg_off of the pair's first read)
     int cap_h, cap_b, cap_u;
+    PairTab ptab;             // host-built insert-size score terms (mem_pair)
 };
 
 // what the pairing stage decides for one pair and the record stage needs back
@@ -387,7 +395,7 @@ __global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPe
 
     bool paired = false;
     if (!(opt.flag & MEM_F_NOPAIRING) && n_pri[0] && n_pri[1]
-        && (o = mem_pair(ix, opt, pes, a[0], a[1], (int)id, &subo, &n_sub, z, n_pri, v, u, cap_u, err)) > 0) {
+        && (o = mem_pair(ix, opt, pes, pv.ptab, a[0], a[1], (int)id, &subo, &n_sub, z, n_pri, v, u, cap_u, err)) > 0) {
         int is_multi[2], q_pe, score_un;
         for (int i = 0; i < 2; ++i) {
             int j;
@@ -612,14 +620,14 @@ void launch_pe_copy_regs(hipStream_t st, const TileView& tv, const AlnReg* src, 
 }
 // mate rescue steps 1 and 2 + the pairing stage.  rescue: RescueJob[cap], KswR[cap], per-pair first/count, a counter (zeroed here)
 void launch_pe_pair(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, AlnReg* regs, const int64_t* reg_off,
-                    int32_t* n_regs, int32_t* ints, void* vpool, uint8_t* scratch, int64_t scratch_per_pair, int cap_h, int cap_b, int cap_u, const MemPestat* pes, void* states,
+                    int32_t* n_regs, int32_t* ints, void* vpool, uint8_t* scratch, int64_t scratch_per_pair, int cap_h, int cap_b, int cap_u, const MemPestat* pes, const PairTab& ptab, void* states,
                     void* rescue_jobs, void* rescue_res, int32_t* rescue_first, int32_t* rescue_num, int32_t* rescue_cnt, int rescue_cap)
 {
     int np = tv.n_reads >> 1;
     hipLaunchKernelGGL(k_pe_tail, dim3(1), dim3(64), 0, st, tv);
     if (np <= 0) return;
     PeView pv; pv.regs = regs; pv.reg_off = reg_off; pv.n_regs = n_regs; pv.ints = ints; pv.vpool = vpool; pv.scratch = scratch;
-    pv.scratch_per_pair = scratch_per_pair; pv.cap_h = cap_h; pv.cap_b = cap_b; pv.cap_u = cap_u;
+    pv.scratch_per_pair = scratch_per_pair; pv.cap_h = cap_h; pv.cap_b = cap_b; pv.cap_u = cap_u; pv.ptab = ptab;
     (void)hipMemsetAsync(rescue_cnt, 0, 4, st);
     if (!(opt.flag & MEM_F_NO_RESCUE)) {
         hipLaunchKernelGGL(k_pe_rescue_plan, dim3((np + 127) / 128), dim3(128), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3],
@@ -644,7 +652,7 @@ void launch_pe_out(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const 
 {
     int np = tv.n_reads >> 1;
     if (np <= 0) return;
-    PeView pv; pv.vpool = 0; pv.scratch = 0; pv.scratch_per_pair = 0; pv.cap_h = pv.cap_b = pv.cap_u = 0;
+    PeView pv = PeView();
     pv.regs = regs; pv.reg_off = reg_off; pv.n_regs = n_regs; pv.ints = ints;
     JobView jv; jv.out = (const DpOut*)job_out; jv.cig = job_cig; jv.cig_cap = cig_cap;
     hipLaunchKernelGGL(k_pe_out, dim3((2 * np + 63) / 64), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3], (const PeState*)states, jv);

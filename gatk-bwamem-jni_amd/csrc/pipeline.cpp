@@ -24,6 +24,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <cmath>
 #include "bwamem_types.h"
 #include "kernels.h"
 #include "index_io.h"
@@ -161,7 +162,8 @@ struct bwaidx_s {
     HostIndex h;
     int device = 0;
     DevIndex d;
-    DevBuf d_occ, d_sa_lo, d_sa_hi, d_pac, d_ann_off, d_ann_len, d_ann_alt, d_name_off, d_names, d_log;
+    DevBuf d_occ, d_sa_lo, d_sa_hi, d_pac, d_ann_off, d_ann_len, d_ann_alt, d_name_off, d_names, d_log, d_ptab;
+    PairTab pair_tab;               // insert-size score terms of the running paired-end call (build_pair_tab)
     std::mutex mu;                  // one call at a time per index/device
     Workspace ws;
     std::vector<Workspace*> extra_ws;   // further tiles in flight (one stream + host thread each)
@@ -258,7 +260,7 @@ static bool upload_index(bwaidx_s* ix)
 static void free_index(bwaidx_s* ix)
 {
     (void)hipSetDevice(ix->device);
-    DevBuf* all[] = { &ix->d_occ, &ix->d_sa_lo, &ix->d_sa_hi, &ix->d_pac, &ix->d_ann_off, &ix->d_ann_len, &ix->d_ann_alt, &ix->d_name_off, &ix->d_names, &ix->d_log };
+    DevBuf* all[] = { &ix->d_occ, &ix->d_sa_lo, &ix->d_sa_hi, &ix->d_pac, &ix->d_ann_off, &ix->d_ann_len, &ix->d_ann_alt, &ix->d_name_off, &ix->d_names, &ix->d_log, &ix->d_ptab };
     for (DevBuf* b : all) b->release();
     ix->ws.release();
     ix->seed_ws.release();
@@ -430,6 +432,42 @@ static void host_pestat(const MemOpt& opt, const std::vector<int8_t>& dir, const
 }
 
 static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes0, bwamem_batch_s* b, int64_t read_id0);
+
+// mem_pair scores a candidate pair with .721 * log(2 erfc(|dist - avg| / std / sqrt 2)) * a (upstream bwamem_pair.c), and the
+// sum is truncated to an int: a decision that depends on libm.  dist is an integer in [low, high], so the host (glibc, the
+// library the reference itself calls) evaluates the term for every distance the call can see and the device indexes the
+// table (k_pe.hip: mem_pair).  Only distances within 40 standard deviations are stored: beyond |ns| / sqrt 2 >= 28 glibc's
+// erfc is exactly 0 and the term is -inf (checked at the clipped ends).
+static bool build_pair_tab(bwaidx_s* ix, const MemPestat* pes)
+{
+    PairTab& pt = ix->pair_tab;
+    memset(&pt, 0, sizeof pt);
+    std::vector<double> tab;
+    const int64_t cap = (int64_t)1 << 24;
+    for (int d = 0; d < 4; ++d) {
+        if (pes[d].failed || pes[d].high < pes[d].low) continue;
+        int64_t lo = pes[d].low, hi = pes[d].high;
+        const double avg = pes[d].avg, sd = pes[d].std;
+        auto term = [&](int64_t dist) { const double ns = (dist - avg) / sd; return log(2. * erfc(fabs(ns) * M_SQRT1_2)); };
+        if (std::isfinite(avg) && std::isfinite(sd) && sd >= 0 && fabs(avg) < 1e15 && sd < 1e13) {
+            const int64_t clo = (int64_t)floor(avg - 40. * sd) - 1, chi = (int64_t)ceil(avg + 40. * sd) + 1;
+            const bool lo_ok = clo <= lo || term(clo) == -INFINITY, hi_ok = chi >= hi || term(chi) == -INFINITY;
+            if (lo_ok && clo > lo) lo = clo;
+            if (hi_ok && chi < hi) hi = chi;
+        }
+        if (hi < lo) continue;
+        if (hi - lo + 1 > cap || (int64_t)tab.size() + (hi - lo + 1) > cap) {
+            fprintf(stderr, "[bwamem_hip] insert-size range [%d, %d] of orientation %d is too wide to tabulate\n", pes[d].low, pes[d].high, d);
+            return false;
+        }
+        pt.lo[d] = lo; pt.n[d] = (int32_t)(hi - lo + 1); pt.off[d] = (int32_t)tab.size();
+        for (int64_t dist = lo; dist <= hi; ++dist) tab.push_back(term(dist));
+    }
+    if (!ix->d_ptab.ensure(tab.size() * 8 + 8)) return false;
+    if (!tab.empty()) HIP_OK(hipMemcpy(ix->d_ptab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    pt.t = ix->d_ptab.as<double>();
+    return true;
+}
 
 struct TileSpec { uint32_t r0, r1; int L; };
 
@@ -804,7 +842,7 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
             pe_rescue_cap = rc;
         }
         TIMED(ws, K_FINAL, launch_pe_pair(ws.stream, ix->d, opt, tv, regs2, reg_off2, tv.n_regs, ws.pe_ints2.as<int32_t>(), ws.pe_vpool.p,
-                                          ws.pe_scratch.as<uint8_t>(), per_pair, cap_h, cap_b, cap_u, pes, ws.pe_states.p,
+                                          ws.pe_scratch.as<uint8_t>(), per_pair, cap_h, cap_b, cap_u, pes, ix->pair_tab, ws.pe_states.p,
                                           ws.pe_rescue[0].p, ws.pe_rescue[1].p, ws.pe_rescue[2].as<int32_t>() + 16, ws.pe_rescue[2].as<int32_t>() + 16 + (T / 2 + 1),
                                           ws.pe_rescue[2].as<int32_t>(), pe_rescue_cap));
         int32_t n_jobs = 0, err = 0, n_rescue = 0;
@@ -860,6 +898,7 @@ static void pe_call_free(bwamem_batch_s* b)
 static bool pe_begin(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes0, bwamem_batch_s* b, int64_t read_id0)
 {
     pe_call_free(b);
+    if (pes0 && !build_pair_tab(ix, pes0)) return false;
     PeCall* pc = b->pe = new PeCall();
     pc->read_id0 = read_id0;
     pc->specs = plan_tiles(b, opt, true, false);
@@ -886,6 +925,7 @@ static bool pe_begin(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes0, bwa
 static bool pe_finish(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, bwamem_batch_s* b)
 {
     if (!b->pe) return false;
+    if (!build_pair_tab(ix, pes)) { pe_call_free(b); return false; }
     const std::vector<TileSpec>& specs = b->pe->specs;
     std::vector<PeTile>& tiles = b->pe->tiles;
     const int64_t read_id0 = b->pe->read_id0;

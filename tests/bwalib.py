@@ -308,3 +308,66 @@ def simulate_pairs(seqs, n_pairs, length=150, seed=43, ins_mean=400, ins_sd=50, 
             r1, r2 = r2, r1
         out += [r1, r2]
     return out
+
+
+def _diverge(rng, seg, sub, indel=0.0):
+    """a diverged copy of a base-code array: substitutions plus a few short indels"""
+    seg = seg.copy()
+    mut = rng.random(len(seg)) < sub
+    seg[mut] = (seg[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) % 4
+    if indel <= 0:
+        return seg
+    out, i = [], 0
+    cuts = np.flatnonzero(rng.random(len(seg)) < indel)
+    for c in cuts:
+        out.append(seg[i:c])
+        if rng.random() < 0.5:
+            i = c + int(rng.integers(1, 6))                                   # deletion
+        else:
+            out.append(rng.integers(0, 4, size=int(rng.integers(1, 6)), dtype=np.uint8)); i = c   # insertion
+    out.append(seg[i:])
+    return np.concatenate(out)
+
+
+def synth_alt_genome(seed=0xA17):
+    """A primary assembly of four contigs plus ALT contigs the way GRCh38 carries them:
+    chr1_alt1 / chr2_alt1 / chr1_alt2 are 2-5 % diverged copies of 20-35 kb of chr1 / chr2 (one reverse-complemented, two
+    overlapping the same source), chrUn_decoy is unrelated sequence listed as ALT, and a 500-base repeat family with seven
+    primary copies also sits inside an ALT source region, so that some reads have more hits than max_XA_hits of which one is ALT.
+    -> (seqs, alt_names, regions) with regions = {name: (contig index, start, end)} of the stretches reads should be drawn from."""
+    rng = np.random.default_rng(seed)
+    base = [("chr%d" % (i + 1), None) for i in range(4)]
+    arr = [rng.integers(0, 4, size=l, dtype=np.uint8) for l in (110000, 80000, 60000, 50000)]
+    fam = arr[0][60000:60500].copy()                                           # the repeat family, founder inside alt1's source
+    spots = [(0, 5000), (1, 3000), (1, 30000), (2, 2000), (2, 20000), (3, 1000), (3, 9000)]
+    for ci, st in spots:
+        if st + 500 < len(arr[ci]):
+            arr[ci][st:st + 500] = _diverge(rng, fam, 0.015)
+    alts = [("chr1_alt1", _diverge(rng, arr[0][40000:75000], 0.03, 0.0005)),
+            ("chr2_alt1", (3 - _diverge(rng, arr[1][10000:35000], 0.02, 0.0005))[::-1]),
+            ("chr1_alt2", _diverge(rng, arr[0][55000:75000], 0.05, 0.001)),
+            ("chrUn_decoy", rng.integers(0, 4, size=8000, dtype=np.uint8))]
+    seqs = [(n, BASES[a].tobytes()) for (n, _), a in zip(base, arr)] + [(n, BASES[a].tobytes()) for n, a in alts]
+    regions = {"chr1_src": (0, 40000, 75000), "chr2_src": (1, 10000, 35000), "family": (0, 60000, 60500),
+               "chr1_alt1": (4, 0, len(alts[0][1])), "chr2_alt1": (5, 0, len(alts[1][1])), "chr1_alt2": (6, 0, len(alts[2][1])),
+               "decoy": (7, 0, 8000)}
+    return seqs, [n for n, _ in alts], regions
+
+
+def write_alt_file(path, alt_names):
+    """<prefix>.alt as bwa-kit ships it: SAM text, '@' header lines, the ALT contig's name in the first column"""
+    with open(path, "w") as f:
+        f.write("@HD\tVN:1.5\tSO:unsorted\n@SQ\tSN:chr1\tLN:1\n")
+        for i, n in enumerate(alt_names):
+            f.write("%s\t%d\tchr1\t%d\t60\t100M\t*\t0\t0\t*\t*\tNM:i:0\n" % (n, 0 if i % 2 == 0 else 16, 1000 * i + 1))
+
+
+def reads_from_regions(seqs, regions, names, n, length=150, seed=1, **kw):
+    """simulate_reads restricted to the named regions"""
+    sub = [(k, seqs[regions[k][0]][1][regions[k][1]:regions[k][2]]) for k in names]
+    return simulate_reads(sub, n, length=length, seed=seed, random_frac=0.0, **kw)
+
+
+def pairs_from_regions(seqs, regions, names, n_pairs, length=100, seed=1, **kw):
+    sub = [(k, seqs[regions[k][0]][1][regions[k][1]:regions[k][2]]) for k in names]
+    return simulate_pairs(sub, n_pairs, length=length, seed=seed, **kw)

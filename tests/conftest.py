@@ -35,11 +35,14 @@ def hip_lib():
     return B.product_lib(emu=False)
 
 
-def _build_genome(lib, workdir, name, total_bp, **kw):
+def _build_genome(lib, workdir, name, total_bp, seqs=None, alt_names=None, **kw):
     import ctypes
     fa = os.path.join(workdir, name + ".fa")
-    seqs = B.synth_genome(total_bp, **kw)
+    if seqs is None:
+        seqs = B.synth_genome(total_bp, **kw)
     B.write_fasta(fa, seqs)
+    if alt_names:
+        B.write_alt_file(fa + ".alt", alt_names)
     build = lib.dll.jnibwa_createReferenceIndex
     build.argtypes = [ctypes.c_char_p] * 3
     assert build(fa.encode(), fa.encode(), b"auto") == 0
@@ -57,3 +60,13 @@ def small_genome(hip_lib, workdir):
 @pytest.fixture(scope="session")
 def medium_genome(hip_lib, workdir):
     return _build_genome(hip_lib, workdir, "g3m", 3000000, n_contigs=6, seed=11, repeat_frac=0.08, n_frac=0.0005)
+
+
+@pytest.fixture(scope="session")
+def alt_genome(hip_lib, workdir):
+    """primary assembly + ALT contigs listed in <prefix>.alt (and the same sequences without the .alt file, for contrast)
+    -> (seqs, img, img_without_alt, alt_names, regions)"""
+    seqs, alt_names, regions = B.synth_alt_genome()
+    _, img = _build_genome(hip_lib, workdir, "galt", 0, seqs=seqs, alt_names=alt_names)
+    _, img0 = _build_genome(hip_lib, workdir, "galt_noalt", 0, seqs=seqs)
+    return seqs, img, img0, alt_names, regions

@@ -114,3 +114,22 @@ def test_emu_dp_rows_in_global_memory(emu, oracle, rota_img, small_genome, monke
     _cmp(emu, oracle, img, reads)
     monkeypatch.delenv("BWAMEM_HIP_DP_ROWS")
     _cmp(emu, oracle, rota_img, [b"ACGT" * 5000, b"ACGT" * 20])
+
+
+ALT_REGIONS = ["chr1_src", "chr2_src", "family", "chr1_alt1", "chr2_alt1", "chr1_alt2", "decoy"]
+
+
+def test_emu_alt_contigs(emu, oracle, alt_genome):
+    """ALT-aware paths (rows a9/a14/a17/a19): is_alt chains, the second round of mem_mark_primary_se, XA has_alt /
+    max_XA_hits_alt, ALT supplementary records, single- and paired-end"""
+    seqs, img, img0, alt_names, regions = alt_genome
+    reads = B.reads_from_regions(seqs, regions, ALT_REGIONS, 40, seed=3, sub=0.01, indel=0.001)
+    _cmp(emu, oracle, img, reads)
+    _cmp(emu, oracle, img, reads[:16], flag=B.MEM_F_ALL)
+    _cmp(emu, oracle, img, reads[:16], max_XA_hits=1, max_XA_hits_alt=3)
+    pairs = B.pairs_from_regions(seqs, regions, ALT_REGIONS[:6], 10, length=100, seed=4, ins_mean=300, ins_sd=30)
+    h, ho = emu.open_index(img), oracle.open_index(img)
+    opts = B.set_opt(emu.default_options(), flag=B.MEM_F_PE)
+    for pes in (None, B.pack_pestat(150, 450, 300.0, 30.0)):
+        assert emu.align_raw(h, opts, B.pack_request(pairs), pes) == oracle.align_raw(ho, opts, B.pack_request(pairs), pes)
+    emu.destroy_index(h); oracle.destroy_index(ho)

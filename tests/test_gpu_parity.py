@@ -345,3 +345,45 @@ def test_parity_reads_beyond_lds_rows(hip_lib, oracle, medium_genome, small_geno
     seqs, img = small_genome                           # the same kernels forced on ordinary reads, many per workgroup
     monkeypatch.setenv("BWAMEM_HIP_DP_ROWS", "hbm")
     _parity(hip_lib, oracle, img, B.simulate_reads(seqs, 3000, length=150, seed=11, sub=0.03, indel=0.005))
+
+
+# ---------------------------------------------------------------- ALT contigs (rows a9 / a14 / a17 / a19)
+ALT_REGIONS = ["chr1_src", "chr2_src", "family", "chr1_alt1", "chr2_alt1", "chr1_alt2", "decoy"]
+
+
+def test_parity_alt_contigs_single_end(hip_lib, oracle, alt_genome):
+    """every production hg38 image carries ALT / decoy / HLA contigs: the is_alt chain-overlap rule, the second round of
+    mem_mark_primary_se (ars_hash2 order, secondary = INT_MAX), XA has_alt / max_XA_hits_alt and ALT supplementary records"""
+    seqs, img, img0, alt_names, regions = alt_genome
+    reads = B.reads_from_regions(seqs, regions, ALT_REGIONS, 4000, seed=3, sub=0.01, indel=0.001)
+    reads += B.reads_from_regions(seqs, regions, ALT_REGIONS, 1000, length=251, seed=4, sub=0.03, indel=0.004)
+    got = _parity(hip_lib, oracle, img, reads)
+    dec = B.decode_response(got, len(reads))
+    n_alt = len(seqs) - len(alt_names)                  # contig ids >= n_alt are ALT
+    assert sum(1 for r in dec for a in r if a["flag"] & 0x800 and a.get("rid", -1) >= n_alt) > 500     # ALT hits reported as supplementary
+    assert sum(1 for r in dec for a in r if any(n in a.get("xa", "") for n in alt_names)) > 300         # ALT hits in XA
+    assert sum(1 for r in dec for a in r if a.get("xa", "").count(";") > 5) > 5                         # has_alt lifts max_XA_hits
+    assert sum(1 for r in dec if r[0].get("rid", -1) < n_alt and r[0]["mapq"] > 0 and len(r) > 1 and r[1].get("rid", -1) >= n_alt) > 300
+    assert _parity(hip_lib, oracle, img0, reads) != got                                                  # the .alt file matters
+    _parity(hip_lib, oracle, img, reads[:1500], flag=B.MEM_F_ALL)
+    _parity(hip_lib, oracle, img, reads[:1500], max_XA_hits=1, max_XA_hits_alt=3)
+    _parity(hip_lib, oracle, img, reads[:1500], max_XA_hits=2, max_XA_hits_alt=2, XA_drop_ratio=0.5, flag=B.MEM_F_NO_MULTI | B.MEM_F_PRIMARY5)
+
+
+def test_parity_alt_contigs_paired_end(hip_lib, oracle, alt_genome):
+    seqs, img, img0, alt_names, regions = alt_genome
+    pairs = B.pairs_from_regions(seqs, regions, ALT_REGIONS[:6], 1500, length=100, seed=4, ins_mean=300, ins_sd=30)
+    import random
+    rnd = random.Random(5)
+    for i in range(1, len(pairs), 6):                     # mates that need rescue next to ALT anchors
+        r = bytearray(pairs[i])
+        for k in range(0, len(r), 7):
+            r[k] = ord("ACGT"[rnd.randrange(4)])
+        pairs[i] = bytes(r)
+    got = _parity_pe(hip_lib, oracle, img, pairs)
+    dec = B.decode_response(got, len(pairs))
+    n_alt = len(seqs) - len(alt_names)
+    assert sum(1 for r in dec for a in r if a["flag"] & 0x800 and a.get("rid", -1) >= n_alt) > 200
+    _parity_pe(hip_lib, oracle, img, pairs, pes=B.pack_pestat(150, 450, 300.0, 30.0))
+    _parity_pe(hip_lib, oracle, img, pairs[:800], flag=B.MEM_F_NO_RESCUE)
+    _parity_pe(hip_lib, oracle, img, pairs[:800], flag=B.MEM_F_ALL, max_XA_hits=1)

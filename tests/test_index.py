@@ -4,6 +4,8 @@ import filecmp
 import os
 import re
 
+import pytest
+
 import bwalib as B
 
 
@@ -77,3 +79,28 @@ def test_host_mirror_error_behaviour(hip_lib, workdir):
     s = bwamem.BwaMemPairEndStats(200, 10, 1, 600)
     assert (s.low, s.high, s.failed) == (1, 600, False) and bwamem.BwaMemPairEndStats.DO_NOT_INFER.failed
     assert "cb950614" in bwamem.BwaMemIndex.getBWAVersion()
+
+
+def test_no_device_libm():
+    """libm stays on the host: decisions that depend on log/erfc read host-built (glibc) tables, so no
+    device object may contain the math library's code.  ocml is linked as bitcode and inlined, so there is no symbol to
+    look for; its double-precision log/erfc/exp are recognisable by v_frexp_* (argument reduction), the single-precision
+    ones by the transcendental unit's instructions."""
+    import glob
+    import subprocess
+    import tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    objs = sorted(glob.glob(os.path.join(B.PKG, "_build", "k_*.o")))
+    if not os.path.exists(objdump) or not objs:
+        pytest.skip("no llvm-objdump / object files (the GPU box carries only the built library)")
+    with tempfile.TemporaryDirectory() as tmp:
+        for o in objs:
+            c = os.path.join(tmp, os.path.basename(o))
+            subprocess.run(["cp", o, c], check=True)
+            subprocess.run([objdump, "--offloading", c], check=True, cwd=tmp, stdout=subprocess.DEVNULL)
+            code = glob.glob(c + ".*gfx950")
+            assert code, "no gfx950 code object in " + o
+            asm = subprocess.run([objdump, "-d", code[0]], check=True, capture_output=True, text=True).stdout
+            assert len(asm) > 10000
+            for ins in ("v_frexp_", "v_log_f", "v_exp_f", "v_sqrt_f", "v_rsq_f", "v_sin_f", "v_cos_f"):
+                assert ins not in asm, "%s contains %s: a device math-library call" % (os.path.basename(o), ins)

@@ -107,3 +107,24 @@ def test_oracle_slice_entry_point_and_response_walker(oracle, rota_img):
     assert [offs[i + 1] - offs[i] for i in range(len(reads))] == [len(x) for x in parts]
     assert ro(want, len(want) - 1, len(reads), offs) == -1           # truncated buffer is reported
     oracle.destroy_index(h)
+
+
+def test_alt_fixture_exercises_alt_paths(oracle, alt_genome):
+    """the ALT fixture (tests/bwalib.py: synth_alt_genome) must actually reach the ALT-only rules: ALT hits as 0x800
+    records after a primary-assembly record, ALT entries in XA, more XA entries than max_XA_hits when one is ALT, and
+    a different response when the same sequences are indexed without the .alt file"""
+    seqs, img, img0, alt_names, regions = alt_genome
+    names = ["chr1_src", "chr2_src", "family", "chr1_alt1", "chr2_alt1", "chr1_alt2", "decoy"]
+    reads = B.reads_from_regions(seqs, regions, names, 400, seed=3, sub=0.01, indel=0.001)
+    n_alt = len(seqs) - len(alt_names)
+    out = {}
+    for image in (img, img0):
+        ho = oracle.open_index(image)
+        out[image] = B.decode_response(oracle.align_raw(ho, oracle.default_options(), B.pack_request(reads)), len(reads))
+        oracle.destroy_index(ho)
+    dec, dec0 = out[img], out[img0]
+    assert sum(1 for r in dec for a in r if a["flag"] & 0x800 and a.get("rid", -1) >= n_alt) > 100
+    assert sum(1 for r in dec0 for a in r if a["flag"] & 0x800) == 0
+    assert sum(1 for r in dec for a in r if any(n in a.get("xa", "") for n in alt_names)) > 50
+    assert sum(1 for r in dec for a in r if a.get("xa", "").count(";") > 5) > 0
+    assert sum(r[0]["mapq"] for r in dec) > sum(r[0]["mapq"] for r in dec0)       # primary-assembly MAPQ no longer diluted by the ALT copy
