@@ -9,9 +9,15 @@ segments; it is indexed on the device by gatk-bwamem-jni_amd/index_build_gpu.py.
 
 A "step" is one pass of the whole hot path (encode -> SMEM seeding -> SA lookup -> chaining ->
 banded extension -> region post-processing -> records -> packed response) over the batch, with
-the request already resident in HBM and the response left in HBM.  One process per GPU; reads
-shard across ranks with no collective (weak scaling: every rank aligns --reads reads); the only
-torch.distributed traffic is the barrier and the max-over-ranks of the elapsed time.
+the request already resident in HBM and the response left in HBM: that rate is `value`.  After
+the timed steps the same batch goes through the drop-in entry point itself,
+jnibwa_createAlignments (pageable host request in, malloc'ed host response out): `host_to_host`.
+One process per GPU; `--gpus N` starts the N ranks itself when no launcher did; reads shard
+across ranks with no collective (weak scaling: every rank aligns --reads reads); the only
+torch.distributed traffic is the barriers and the gather of the ranks' elapsed times.
+--genome humanlike swaps the i.i.d. reference for one with human-like repeat content; --image /
+BWAHIP_REF_IMG uses an existing index image (reads sampled from its packed reference);
+LIBBWA_PATH / BWA_ORACLE_SRC make a stock libbwa the CPU baseline and parity checker.
 """
 import argparse
 import ctypes
@@ -77,6 +83,119 @@ def synth_genome(torch, dev, total_bp, n_contigs, seed):
         seg = codes[src:src + l].clone()
         mut = torch.rand(l, generator=g, device=dev) < 0.03
         seg = torch.where(mut, (seg + torch.randint(1, 4, (l,), dtype=torch.uint8, generator=g, device=dev)) % 4, seg)
+        if int(torch.randint(0, 2, (1,), generator=hg)):
+            seg = torch.flip(3 - seg, [0])
+        codes[dst:dst + l] = seg
+        done += l
+    contigs = [("chr%d" % (i + 1), int(lens[i])) for i in range(n_contigs)]
+    return codes, contigs
+
+
+def genome_from_index(torch, dev, lib, idx):
+    """--image / BWAHIP_REF_IMG: base codes and contig table of an existing index image, taken from its packed reference
+    on the device (ambiguous stretches hold whatever random bases the indexer put there, as in any .pac)"""
+    lib.bwamem_hip_index_contig_lengths.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    lib.bwamem_hip_index_unpack_pac.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    n = lib.bwamem_hip_index_contig_lengths(idx, None, 0)
+    lens = (ctypes.c_int64 * max(n, 1))()
+    lib.bwamem_hip_index_contig_lengths(idx, lens, n)
+    total = sum(lens[i] for i in range(n))
+    codes = torch.empty(total, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    if lib.bwamem_hip_index_unpack_pac(idx, 0, total, codes.data_ptr()) != 0:
+        raise SystemExit("cannot unpack the image's reference")
+    return codes, [("ctg%d" % i, int(lens[i])) for i in range(n)]
+
+
+def _mutate(torch, g, dev, seg, rate):
+    """substitutions at a per-row rate (rate: scalar or (rows, 1) tensor)"""
+    mut = torch.rand(seg.shape, generator=g, device=dev) < rate
+    return torch.where(mut, (seg + torch.randint(1, 4, seg.shape, dtype=torch.uint8, generator=g, device=dev)) % 4, seg)
+
+
+def synth_genome_humanlike(torch, dev, total_bp, n_contigs, seed):
+    """A harder reference than synth_genome: about 45 % of the bases belong to repeat families laid out the way a human
+    genome has them, so that seeds hit many places, max_occ sampling and frac_rep come into play, and reads carry several
+    chains.  Fractions scale with total_bp (figures for 3.1 Gbp):
+      * SINE-like: one 300-base consensus with an A-rich tail, ~1.1 M copies at 8-16 % divergence           (~10.5 %)
+      * LINE-like: one 6-kb consensus, ~0.5 M copies, 5'-truncated (5 % full length), 3-20 % divergence      (~17 %)
+      * older dispersed families: 40 consensi of 200-900 bases, 20-30 % divergence                           (~8 %)
+      * satellite arrays: one 171-base monomer in 12-monomer higher-order repeats, 1-3 Mbp per contig, 1.5 % (~1.5 %)
+      * microsatellites / low complexity: 1-6 base units, 20-80 bases                                        (~1 %)
+      * segmental duplications: 10-100 kb blocks copied at 1-3 % divergence                                  (~5 %)
+    over i.i.d. bases with 41 % GC.  Seeded and device-side like synth_genome."""
+    g = torch.Generator(device=dev); g.manual_seed(seed ^ 0x48554D)
+    hg = torch.Generator(); hg.manual_seed(seed + 7)
+    w = torch.rand(n_contigs, generator=g, device=dev) + 0.5
+    lens = (w / w.sum() * total_bp).long()
+    lens[-1] += total_bp - int(lens.sum())
+    codes = torch.empty(total_bp, dtype=torch.uint8, device=dev)
+    lut = torch.tensor([0] * 295 + [1] * 205 + [2] * 205 + [3] * 295, dtype=torch.uint8, device=dev)     # A/T 29.5 %, C/G 20.5 %
+    for lo in range(0, total_bp, 1 << 28):
+        hi = min(total_bp, lo + (1 << 28))
+        codes[lo:hi] = lut[torch.randint(0, 1000, (hi - lo,), generator=g, device=dev)]
+    scale = total_bp / 3.1e9
+
+    def rand_consensus(n):
+        return lut[torch.randint(0, 1000, (n,), generator=g, device=dev)]
+
+    def scatter_family(cons, n_copies, div_lo, div_hi, min_len, full_frac, chunk):
+        """copies of cons (3' end kept, 5' end truncated to a random length >= min_len unless full) at random places and strands"""
+        Lc = cons.numel()
+        col = torch.arange(Lc, device=dev)
+        for c0 in range(0, n_copies, chunk):
+            m = min(chunk, n_copies - c0)
+            ln = torch.where(torch.rand(m, generator=g, device=dev) < full_frac, torch.full((m,), Lc, device=dev),
+                             (torch.rand(m, generator=g, device=dev) * (Lc - min_len)).long() + min_len)
+            seg = _mutate(torch, g, dev, cons[None, :].expand(m, Lc), (torch.rand(m, 1, generator=g, device=dev) * (div_hi - div_lo) + div_lo))
+            rc = torch.rand(m, generator=g, device=dev) < 0.5
+            seg = torch.where(rc[:, None], torch.flip(3 - seg, [1]), seg)
+            keep = torch.where(rc[:, None], col[None, :] < ln[:, None], col[None, :] >= (Lc - ln)[:, None])      # the kept end
+            pos = (torch.rand(m, generator=g, device=dev, dtype=torch.float64) * (total_bp - Lc - 1)).long()
+            dst = pos[:, None] + col[None, :]
+            codes[dst[keep]] = seg[keep]
+
+    # older dispersed families first (younger ones overwrite them, as insertions do)
+    for _ in range(40):
+        Lc = int(torch.randint(200, 900, (1,), generator=hg))
+        scatter_family(rand_consensus(Lc), int(0.08 * total_bp / 40 / (0.75 * Lc)), 0.20, 0.30, Lc // 2, 0.5, 1 << 16)
+    line = rand_consensus(6000)
+    scatter_family(line, int(0.17 * total_bp / 1050), 0.03, 0.20, 300, 0.05, 1 << 13)
+    sine = rand_consensus(300)
+    sine[-24:] = 0                                                                  # A-rich tail
+    scatter_family(sine, int(0.105 * total_bp / 295), 0.08, 0.16, 250, 0.9, 1 << 17)
+    # microsatellites / low complexity
+    n_ms = int(0.01 * total_bp / 50)
+    col = torch.arange(80, device=dev)
+    for c0 in range(0, n_ms, 1 << 18):
+        m = min(1 << 18, n_ms - c0)
+        ul = torch.randint(1, 7, (m,), generator=g, device=dev)
+        unit = torch.randint(0, 4, (m, 6), dtype=torch.uint8, generator=g, device=dev)
+        ln = torch.randint(20, 81, (m,), generator=g, device=dev)
+        seg = torch.gather(unit, 1, (col[None, :] % ul[:, None]))
+        seg = _mutate(torch, g, dev, seg, 0.02)
+        pos = (torch.rand(m, generator=g, device=dev, dtype=torch.float64) * (total_bp - 100)).long()
+        keep = col[None, :] < ln[:, None]
+        codes[(pos[:, None] + col[None, :])[keep]] = seg[keep]
+    # satellite arrays: one per contig
+    mono = rand_consensus(171)
+    hor = torch.cat([_mutate(torch, g, dev, mono, 0.2) for _ in range(12)])
+    off = 0
+    for i in range(n_contigs):
+        cl = int(lens[i])
+        al = int(min(cl // 4, (1_000_000 + int(torch.randint(0, 2_000_000, (1,), generator=hg))) * min(1.0, scale * 1.0 + 0.0)))
+        if al > 4000:
+            st = off + int(torch.randint(0, max(1, cl - al), (1,), generator=hg))
+            arr = hor[torch.arange(al, device=dev) % hor.numel()]
+            codes[st:st + al] = _mutate(torch, g, dev, arr, 0.015)
+        off += cl
+    # segmental duplications
+    n_sd = int(0.05 * total_bp)
+    done = 0
+    while done < n_sd and total_bp > 400000:
+        l = int(torch.randint(10000, min(100000, total_bp // 8), (1,), generator=hg))
+        src = int(torch.randint(0, total_bp - l, (1,), generator=hg)); dst = int(torch.randint(0, total_bp - l, (1,), generator=hg))
+        seg = _mutate(torch, g, dev, codes[src:src + l].clone(), 0.01 + 0.02 * float(torch.rand(1, generator=hg)))
         if int(torch.randint(0, 2, (1,), generator=hg)):
             seg = torch.flip(3 - seg, [0])
         codes[dst:dst + l] = seg
@@ -176,16 +295,20 @@ def synth_long_reads(torch, dev, codes, contigs, n, length, seed):
     return payload
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node; > 1 without a launcher: this process starts them itself")
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--genome-bp", type=int, default=3_100_000_000)
     ap.add_argument("--contigs", type=int, default=24)
-    ap.add_argument("--cpu-sample", type=int, default=600_000, help="reads timed through the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--genome", choices=["iid", "humanlike"], default="iid", help="iid: i.i.d. bases + 5 %% diverged copies (SURVEY.md 8(d)); humanlike: "
+                    "~45 %% of the bases in repeat families (SINE-, LINE-like, satellites, low complexity)")
+    ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads timed through the CPU checker (rank 0, N=1), best of --cpu-reps")
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--h2h-calls", type=int, default=3, help="whole-batch jnibwa_createAlignments calls (host request in, host response out) after the timed steps; the first one sizes buffers, the best of the rest is reported; 0 = skip")
     ap.add_argument("--paired", action="store_true", help="auxiliary measurement (BASELINE.json config 2): --reads is then the number of reads = 2 x pairs; "
                     "the library infers the insert-size statistics per call; metric/roofline fields are still reported for the seeding kernel")
     ap.add_argument("--ont", action="store_true", help="auxiliary measurement (BASELINE.json config 5): ONT-style error model (8 %% substitutions, 3 %% insertions, "
@@ -194,16 +317,52 @@ def main():
                     "proper-pair statistics) instead of inferred per call; the call is then a single pass over the tiles")
     ap.add_argument("--keep-image", default=None, help="also copy the index image to this path (profiling helper)")
     ap.add_argument("--dump-request", default=None, help="write the first --cpu-sample reads as a request file (profiling helper)")
-    ap.add_argument("--image", default=None, help="use an existing .img (e.g. GATK's Homo_sapiens_assembly38.fasta.img) instead of the synthetic genome")
-    args = ap.parse_args()
+    ap.add_argument("--image", default=os.environ.get("BWAHIP_REF_IMG"), help="use an existing .img (e.g. GATK's Homo_sapiens_assembly38.fasta.img) instead of "
+                    "the synthetic genome; reads are sampled from its packed reference (default: $BWAHIP_REF_IMG)")
+    return ap.parse_args()
+
+
+def launch_ranks(n):
+    """`bench.py --gpus N` without a launcher: start N ranks (one per GPU) as child processes BEFORE this process imports
+    torch or touches HIP (a process that has initialised the GPU must never exec or fork GPU work), relay their output
+    (rank 0 prints the JSON line) and fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for r, pr in enumerate(procs):
+        c = pr.wait()
+        if c != 0:
+            print("[bench] rank %d exited with code %d" % (r, c), file=sys.stderr, flush=True)
+            rc = rc or c or 1
+    if rc:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    sys.exit(rc)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args.gpus)
 
     import torch
     import numpy as np
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus) and rank == 0:
+        print("[bench] --gpus %d but the launcher started %d ranks: reporting n_gpus = %d" % (args.gpus, world, world), file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    # BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend -- exercises the N > 1 code path (shared image, barriers,
-    # max-over-ranks timing) on a one-GPU box; not a measurement
+    # BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend -- exercises the N > 1 code path (launcher, shared image,
+    # barriers, max-over-ranks timing) on a one-GPU box; not a measurement
     rehearsal = bool(os.environ.get("BENCH_REHEARSAL"))
     if rehearsal:
         local = 0
@@ -221,26 +380,35 @@ def main():
 
     # ---- reference + index (not timed)
     t0 = time.time()
-    if args.image:
-        img = args.image
-        raise SystemExit("--image needs the packed reference to sample reads from; not wired yet")
+
     def note(msg):
         if rank == 0:
             print("[bench] %6.1fs %s" % (time.time() - t0, msg), file=sys.stderr, flush=True)
-    codes, contigs = synth_genome(torch, dev, args.genome_bp, args.contigs, 0x5EED)
-    note("synthetic genome ready")
-    # every rank holds the same genome (it samples its own reads from it); the index is built once, by rank 0, and the
-    # image file is shared: one copy in the page cache of the node instead of one per rank
-    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
-    img = os.path.join(tmpdir, "bwamem_hip_bench_%s.img" % (os.environ.get("MASTER_PORT", "p") + "_" + str(os.getppid()) if world > 1 else str(os.getpid())))
-    if rank == 0:
-        import index_build_gpu as G
-        pieces = G.build_pieces(codes)
-        note("suffix array / BWT / occ / SA built on the device")
-        G.write_image(img, pieces, contigs)
-        del pieces
-        torch.cuda.empty_cache()
-        note("index image written (%.2f GB)" % (os.path.getsize(img) / 1e9))
+
+    own_image = not args.image
+    if args.image:
+        img = args.image
+        genome_desc = "reference image %s" % os.path.basename(img)
+    else:
+        if args.genome == "humanlike":
+            codes, contigs = synth_genome_humanlike(torch, dev, args.genome_bp, args.contigs, 0x5EED)
+            genome_desc = "synthetic human-like GRCh38-scale genome (%d bp, %d contigs, ~45%% of the bases in repeat families)" % (args.genome_bp, args.contigs)
+        else:
+            codes, contigs = synth_genome(torch, dev, args.genome_bp, args.contigs, 0x5EED)
+            genome_desc = "synthetic GRCh38-scale genome (%d bp, %d contigs, 5%% diverged repeats)" % (args.genome_bp, args.contigs)
+        note("synthetic genome ready")
+        # every rank holds the same genome (it samples its own reads from it); the index is built once, by rank 0, and the
+        # image file is shared: one copy in the page cache of the node instead of one per rank
+        tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        img = os.path.join(tmpdir, "bwamem_hip_bench_%s.img" % (os.environ.get("MASTER_PORT", "p") + "_" + str(os.getppid()) if world > 1 else str(os.getpid())))
+        if rank == 0:
+            import index_build_gpu as G
+            pieces = G.build_pieces(codes)
+            note("suffix array / BWT / occ / SA built on the device")
+            G.write_image(img, pieces, contigs)
+            del pieces
+            torch.cuda.empty_cache()
+            note("index image written (%.2f GB)" % (os.path.getsize(img) / 1e9))
     if dist is not None:
         dist.barrier()
     t_index = time.time() - t0
@@ -250,6 +418,11 @@ def main():
         raise SystemExit("openIndex failed")
     if dist is not None:
         dist.barrier()                       # every rank has the image mapped: rank 0 may unlink it at the end
+    if args.image:                           # reads are sampled from the image's own packed reference
+        codes, contigs = genome_from_index(torch, dev, lib, idx)
+        args.genome_bp = int(codes.numel())
+        args.contigs = len(contigs)
+        note("packed reference of the image unpacked on the device (%d bp, %d contigs)" % (args.genome_bp, args.contigs))
 
     # ---- request resident in HBM (not timed)
     L, R = args.read_len, args.reads
@@ -290,6 +463,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def gather_times(x):
+        """every rank's value of x -> list on every rank (the only torch.distributed traffic besides the barriers)"""
+        if dist is None:
+            return [x]
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
     for _ in range(args.warmup):
         step()
     lib.bwamem_hip_stats_enable(1)
@@ -299,12 +481,48 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.time() - t1
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed_own = time.time() - t1
+    per_rank = gather_times(elapsed_own)
+    elapsed = max(per_rank)
     st_timed = Stats(); lib.bwamem_hip_stats_get(ctypes.byref(st_timed))
+    lib.bwamem_hip_stats_enable(0)
+    result_bytes = lib.bwamem_hip_batch_result_bytes(batch)
+
+    # ---- the same batch through the drop-in entry point itself: jnibwa_createAlignments, host request in, malloc'ed host
+    # response out (jnibwa.c:197-235) -- every rank at once, so that at N > 1 the ranks share the host's memory and PCIe
+    # like N GATK executors would.  Reported next to `value`, never as `value` (which is quoted with the request resident).
+    h2h = None
+    if args.h2h_calls > 0:
+        full = np.empty(4 + R * (L + 1), dtype=np.uint8)
+        full[:4] = np.frombuffer(struct.pack("<i", R), dtype=np.uint8)
+        full[4:] = payload.reshape(-1).cpu().numpy()
+        resident = None
+        if rank == 0:
+            resident = np.empty(max(result_bytes, 1), dtype=np.uint8)
+            if lib.bwamem_hip_batch_download(batch, resident.ctypes.data) != 0:
+                raise SystemExit("download failed")
+        secs, same, h2h_bytes = [], None, 0
+        for k in range(args.h2h_calls):
+            sz = ctypes.c_size_t()
+            barrier()
+            tj = time.time()
+            gp = lib.jnibwa_createAlignments(idx, opts, pes, full.ctypes.data, ctypes.byref(sz))
+            dt = time.time() - tj
+            if not gp:
+                raise SystemExit("jnibwa_createAlignments failed")
+            secs.append(max(gather_times(dt)))
+            h2h_bytes = sz.value
+            if rank == 0 and k == args.h2h_calls - 1 and (not args.paired or pes is not None or True):
+                got = np.ctypeslib.as_array(ctypes.cast(gp, ctypes.POINTER(ctypes.c_ubyte)), shape=(max(sz.value, 1),))
+                same = bool(sz.value == result_bytes and np.array_equal(got[:sz.value], resident[:result_bytes]))
+            lib.jnibwa_free(gp)
+        best = min(secs[1:]) if len(secs) > 1 else secs[0]
+        h2h = {"reads_per_s": world * R / best, "seconds_per_call": [round(x, 4) for x in secs], "calls": args.h2h_calls,
+               "request_bytes_per_gpu": int(full.nbytes), "response_bytes_per_gpu": int(h2h_bytes), "identical_to_resident_response": same,
+               "what": "jnibwa_createAlignments on the whole batch: pageable host request in, malloc'ed host response out, PCIe both ways; "
+                       "max over ranks per call, first call sizes buffers, best of the rest"}
+        del full, resident
+
     # keep the records of the LAST reads of the timed batch (four tiles and a seeding chunk in flight) for the parity check below
     tail_bytes, S2 = None, 0
     if rank == 0 and world == 1 and args.cpu_sample > 0 and (not args.paired or pes is not None):   # (paired with inferred statistics: the batch-wide ones differ from a slice's)
@@ -330,6 +548,7 @@ def main():
     streams_env = os.environ.get("BWAMEM_HIP_STREAMS")
     os.environ["BWAMEM_HIP_STREAMS"] = "1"
     os.environ["BWAMEM_HIP_SEED_AHEAD"] = "0"            # seeding chunks strictly between the tiles, nothing else on the GPU
+    lib.bwamem_hip_stats_enable(1)
     lib.bwamem_hip_stats_reset()
     step()
     torch.cuda.synchronize()
@@ -340,7 +559,6 @@ def main():
     else:
         os.environ["BWAMEM_HIP_STREAMS"] = streams_env
     lib.bwamem_hip_stats_enable(0)
-    result_bytes = lib.bwamem_hip_batch_result_bytes(batch)
 
     out = None
     if rank == 0:
@@ -355,26 +573,33 @@ def main():
         # FETCH_SIZE measured by tests/gpu_units/pmc_seed.sh on this workload (committed summary, see profiles/README.md)
         # is scaled to this launch's extension count
         traffic, traffic_note = None, None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_k_seed.json")) as f:
-                pmc = json.load(f)
-            traffic = pmc["fetch_bytes_per_ext"] * st.n_ext / n_launch
-            traffic_note = pmc.get("note")
-        except (OSError, KeyError, ValueError):
-            pass
+        for name in ("r02_pmc_k_seed.json", "r01_pmc_k_seed.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    pmc = json.load(f)
+                traffic = pmc["fetch_bytes_per_ext"] * st.n_ext / n_launch
+                traffic_note = pmc.get("note")
+                break
+            except (OSError, KeyError, ValueError):
+                pass
+        nr = max(1, st.n_reads)
         out = {
             "metric": "150bp reads aligned/sec vs GRCh38-scale reference (1/2/4/8 MI355X)", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32/int64", "data": "synthetic",
-            "config": {"workload": "%d x %dbp %s synthetic reads per GPU vs synthetic GRCh38-scale genome (%d bp, %d contigs, 5%% diverged repeats), full index in HBM" % (R, L, "paired-end (2 x %d pairs)" % (R // 2) if args.paired else "single-end ONT-style (8 %% sub, 3 %% ins, 3 %% del)" if args.ont else "single-end", args.genome_bp, args.contigs),
-                       "reads_per_gpu": R, "read_len": L, "genome_bp": args.genome_bp, "index_build_s": round(t_index, 1), "response_bytes": result_bytes,
-                       "parallelism": "read-sharded x%d, no collectives" % world, "paired_end": bool(args.paired), "insert_size_statistics": ("supplied " + args.pestat) if (args.paired and args.pestat) else ("inferred per call" if args.paired else None)},
+            "config": {"workload": "%d x %dbp %s synthetic reads per GPU vs %s, full index in HBM" % (R, L, "paired-end (2 x %d pairs)" % (R // 2) if args.paired else "single-end ONT-style (8 %% sub, 3 %% ins, 3 %% del)" if args.ont else "single-end", genome_desc),
+                       "reads_per_gpu": R, "read_len": L, "genome_bp": args.genome_bp, "genome": "image" if args.image else args.genome, "index_build_s": round(t_index, 1), "response_bytes": result_bytes,
+                       "parallelism": "read-sharded x%d, no collectives" % world, "paired_end": bool(args.paired), "insert_size_statistics": ("supplied " + args.pestat) if (args.paired and args.pestat) else ("inferred per call" if args.paired else None),
+                       "value_is": "device-resident rate: request already in HBM when the timed region starts, response left in HBM (the bench contract); the rate through jnibwa_createAlignments itself is `host_to_host`"},
+            "per_rank": {"reads_per_s": [R * args.steps / x for x in per_rank], "ms_per_step_min": min(per_rank) / args.steps * 1e3, "ms_per_step_max": max(per_rank) / args.steps * 1e3},
+            "host_to_host": h2h,
             "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_note, "measured_in": "extra untimed step with nothing else on the GPU: one tile in flight, seeding chunks not overlapped (see DESIGN.md section 5)", "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": int(st.n_launch_seed),
-                         "n_ext_per_read": st.n_ext / max(1, st.n_reads)},
+                         "n_ext_per_read": st.n_ext / nr},
             "kernel_ms_isolated_pass": {k: round(v, 2) for k, v in kern.items()},
             "tiles_in_flight_timed": int(os.environ.get("BWAMEM_HIP_STREAMS", "4")),
             "counters": {"n_ext": int(st.n_ext), "n_lf": int(st.n_lf), "n_sa": int(st.n_sa), "n_dp_cells": int(st.n_dp_cells), "tiles": int(st.n_tiles), "retries": int(st.n_retries)},
+            "per_read": {"ext": st.n_ext / nr, "sa_lookups": st.n_sa / nr, "dp_cells": st.n_dp_cells / nr, "response_bytes": result_bytes / max(1, R)},
         }
 
     # ---- CPU baseline + parity sample (rank 0, N = 1 only)
@@ -382,7 +607,10 @@ def main():
         import bwalib as B
         if not os.path.exists(B.ORACLE_LIB):
             B.build_oracle()
-        orc = B.oracle_lib()
+        orc, kind, kind_note = B.oracle_lib(), "port", "oracle/ (own CPU restatement, not libbwa)"
+        stock = B.stock_libbwa()               # LIBBWA_PATH / BWA_ORACLE_SRC: a stock libbwa behind the same jnibwa_* ABI, when the run environment has one
+        if stock is not None:
+            orc, kind, kind_note = stock, "reference", "stock libbwa (%s)" % stock.path
         S = min(args.cpu_sample, R)
         req = struct.pack("<i", S) + payload[:S].cpu().numpy().tobytes()
         # the GPU box hands one GPU's share of the host to this process (16 cores); stay inside it
@@ -391,14 +619,15 @@ def main():
         oo = B.set_opt(orc.default_options(), n_threads=cores)
         if args.paired:
             B.set_opt(oo, flag=B.get_opt(oo, "flag") | B.MEM_F_PE)
-        tc = time.time()
-        want = orc.align_raw(ho, oo, req, pes)
-        tcpu = time.time() - tc
+        tcs = []
+        for _ in range(max(1, args.cpu_reps)):
+            tc = time.time()
+            want = orc.align_raw(ho, oo, req, pes)
+            tcs.append(time.time() - tc)
+        tcpu = min(tcs)
         orc.destroy_index(ho)
         rb = ctypes.create_string_buffer(req, len(req)); sz = ctypes.c_size_t()
-        tj = time.time()
         gp = lib.jnibwa_createAlignments(idx, opts, pes, rb, ctypes.byref(sz))
-        tj = time.time() - tj
         got = ctypes.string_at(gp, sz.value) if gp else None
         if gp:
             lib.jnibwa_free(gp)
@@ -407,10 +636,10 @@ def main():
             a, b = B.split_response(got, S), B.split_response(want, S)
             ident = sum(1 for x, y in zip(a, b) if x == y) / S
         # second sample: the LAST reads of the batch, taken from the big batch's own response (so the seeding chunks, tiles
-        # and interval-store reuse of a 10 M-read call are what is being checked), against the oracle run on that slice
+        # and interval-store reuse of a 10 M-read call are what is being checked), against the checker run on that slice
         # with its position in the call (the tie-breaking hash of mem_mark_primary_se uses the read index)
         tail = None
-        if tail_bytes is not None and hasattr(orc.dll, "oracle_createAlignmentsAt"):
+        if tail_bytes is not None and kind == "port" and hasattr(orc.dll, "oracle_createAlignmentsAt"):
             req2 = struct.pack("<i", S2) + payload[R - S2:].cpu().numpy().tobytes()
             fn = orc.dll.oracle_createAlignmentsAt
             fn.restype = ctypes.c_void_p
@@ -424,30 +653,17 @@ def main():
             if want2 is not None:
                 a2, b2 = B.split_response(tail_bytes, S2), B.split_response(want2, S2)
                 tail = {"reads": S2, "from": "the last reads of the timed batch's own response", "frac_identical_records": sum(1 for x, y in zip(a2, b2) if x == y) / S2}
-        out["cpu_baseline"] = {"value": S / tcpu, "unit": "reads/s", "cores": cores, "kind": "port",
-                               "sample": "first %d reads of the same batch through oracle/ (own CPU restatement, not libbwa), %d threads, %.1f s" % (S, cores, tcpu)}
-        out["parity_sample"] = {"reads": S, "frac_identical_records": ident}
-        # the drop-in entry point itself on the same sample: host request in, host response out (upload, alignment, download)
-        out["jni_call_host_to_host"] = {"reads": S, "reads_per_s": S / tj if tj > 0 else None, "note": "jnibwa_createAlignments, PCIe both ways included; never `value`"}
+        out["cpu_baseline"] = {"value": S / tcpu, "unit": "reads/s", "cores": cores, "kind": kind,
+                               "sample": "first %d reads of the same batch through %s, %d threads, best of %d runs (%s s)" % (S, kind_note, cores, len(tcs), ", ".join("%.1f" % x for x in tcs))}
+        out["parity_sample"] = {"reads": S, "frac_identical_records": ident, "checker": kind_note}
         if tail is not None:
             out["parity_sample_tail"] = tail
-        if os.environ.get("BENCH_JNI_FULL"):     # the whole batch through the drop-in entry point (host request in, host response out), twice: first call sizes the workspaces
-            full = struct.pack("<i", R) + payload.cpu().numpy().tobytes()
-            fb = ctypes.create_string_buffer(full, len(full)); del full
-            ts = []
-            for _ in range(2):
-                fz = ctypes.c_size_t(); t1 = time.time()
-                fp = lib.jnibwa_createAlignments(idx, opts, pes, fb, ctypes.byref(fz))
-                ts.append(time.time() - t1)
-                if fp:
-                    lib.jnibwa_free(fp)
-            out["jni_call_host_to_host_full_batch"] = {"reads": R, "seconds": [round(t, 4) for t in ts], "reads_per_s": R / ts[-1], "response_bytes": fz.value}
 
     if rank == 0:
         print(json.dumps(out), flush=True)
     lib.bwamem_hip_batch_free(batch)
     lib.jnibwa_destroyIndex(idx)
-    if rank == 0:                            # (the other ranks mapped it before the barrier above; an unlinked file lives until unmapped)
+    if rank == 0 and own_image:              # (the other ranks mapped it before the barrier above; an unlinked file lives until unmapped)
         try:
             os.unlink(img)
         except OSError:

@@ -78,6 +78,7 @@ struct DevIndex {
     uint64_t primary, L2[5], seq_len;
     int64_t  l_pac;
     int32_t  n_seqs, sa_intv, log_tab_n, sa_shift;   // sa_intv = 1 << sa_shift
+    int32_t  n_cu, lds_bytes;                        // of the device the index lives on (launch geometry; host side only)
 };
 
 struct Intv { uint64_t x0, x1, size, info; };          // info = start<<32 | end

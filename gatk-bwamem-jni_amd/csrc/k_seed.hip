@@ -411,6 +411,105 @@ __global__ void __launch_bounds__(1024) k_scan(const int32_t* in, int64_t* out, 
     if (t == 0) out[n] = carry;
 }
 
+// ---- multi-block form of the scan above (launch_scan)
+DEV int64_t block_excl_scan_256(int64_t v, int64_t* lds4, int64_t& total)
+{   // exclusive prefix of v over the 256 threads of a workgroup (4 waves); total = sum over the workgroup
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int64_t incl = v;
+    for (int o = 1; o < 64; o <<= 1) { int64_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    if (lane == 63) lds4[wv] = incl;
+    __syncthreads();
+    int64_t pre = 0; total = 0;
+    for (int w = 0; w < 4; ++w) { const int64_t x = lds4[w]; if (w < wv) pre += x; total += x; }
+    __syncthreads();
+    return pre + incl - v;
+}
+__global__ void __launch_bounds__(256) k_scan_part(const int32_t* in, int n, int64_t* part)
+{
+    __shared__ int64_t w4[4];
+    const int i0 = blockIdx.x * 4096 + threadIdx.x * 16;
+    int64_t sum = 0;
+    for (int k = 0; k < 16; k += 4) {
+        const int i = i0 + k;
+        if (i + 3 < n) { const int4 q = *(const int4*)(in + i); sum += (int64_t)q.x + q.y + q.z + q.w; }
+        else for (int j = i; j < n && j < i + 4; ++j) sum += in[j];
+    }
+    int64_t tot;
+    (void)block_excl_scan_256(sum, w4, tot);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(1024) k_scan_top(int64_t* part, int nb, int64_t* total_out)
+{   // in-place exclusive scan of the block sums (nb is small: n / 4096)
+    __shared__ int64_t wtot[16];
+    __shared__ int64_t carry_s;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + t;
+        const int64_t v = i < nb ? part[i] : 0;
+        int64_t incl = v;
+        for (int o = 1; o < 64; o <<= 1) { int64_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        int64_t pre = carry_s, tot = 0;
+        for (int w = 0; w < 16; ++w) { const int64_t x = wtot[w]; if (w < wv) pre += x; tot += x; }
+        if (i < nb) part[i] = pre + incl - v;
+        __syncthreads();
+        if (t == 0) carry_s += tot;
+        __syncthreads();
+    }
+    if (t == 0) *total_out = carry_s;
+}
+__global__ void __launch_bounds__(256) k_scan_apply(const int32_t* in, int n, const int64_t* part, int64_t* out)
+{
+    __shared__ int64_t w4[4];
+    const int i0 = blockIdx.x * 4096 + threadIdx.x * 16;
+    int v[16];
+    int64_t sum = 0;
+    for (int k = 0; k < 16; ++k) { v[k] = i0 + k < n ? in[i0 + k] : 0; sum += v[k]; }
+    int64_t tot;
+    int64_t run = part[blockIdx.x] + block_excl_scan_256(sum, w4, tot);
+    for (int k = 0; k < 16; ++k) { if (i0 + k < n) out[i0 + k] = run; run += v[k]; }
+}
+
+// ---- read offsets of a stretch of the request, found on the device (launch_nul_offsets)
+DEV uint32_t zero_byte_mask(uint32_t w) { return ~(((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w | 0x7f7f7f7fu); }   // 0x80 in every byte of w that is 0
+DEV void nul_words(const uint8_t* seq, int64_t n_bytes, int64_t b0, uint32_t m[4])
+{   // zero-byte masks of the 16 bytes at b0 (16-byte aligned; the buffer has >= 64 bytes of slack), bytes >= n_bytes ignored
+    const uint4 q = *(const uint4*)(seq + b0);
+    const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+    for (int k = 0; k < 4; ++k) {
+        const int64_t left = n_bytes - (b0 + 4 * k);
+        uint32_t z = zero_byte_mask(w[k]);
+        if (left < 4) z = left <= 0 ? 0u : z & (0xffffffffu >> (8 * (4 - (int)left)));
+        m[k] = z;
+    }
+}
+__global__ void __launch_bounds__(256) k_nul_count(const uint8_t* seq, int64_t n_bytes, int32_t* cnt)
+{
+    __shared__ int64_t w4[4];
+    const int64_t b0 = (int64_t)blockIdx.x * 4096 + threadIdx.x * 16;
+    uint32_t m[4] = { 0, 0, 0, 0 };
+    if (b0 < n_bytes) nul_words(seq, n_bytes, b0, m);
+    int64_t tot;
+    (void)block_excl_scan_256((int64_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3])), w4, tot);
+    if (threadIdx.x == 0) cnt[blockIdx.x] = (int32_t)tot;
+}
+__global__ void __launch_bounds__(256) k_nul_write(const uint8_t* seq, int64_t n_bytes, const int64_t* blk_off, int nb, int64_t* off, int64_t n_reads_max, int64_t* n_found)
+{
+    __shared__ int64_t w4[4];
+    const int64_t b0 = (int64_t)blockIdx.x * 4096 + threadIdx.x * 16;
+    uint32_t m[4] = { 0, 0, 0, 0 };
+    if (b0 < n_bytes) nul_words(seq, n_bytes, b0, m);
+    int64_t tot;
+    int64_t k = blk_off[blockIdx.x] + block_excl_scan_256((int64_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3])), w4, tot);
+    for (int w = 0; w < 4; ++w)
+        for (int j = 0; j < 4; ++j)
+            if (m[w] >> (8 * j + 7) & 1) { if (k < n_reads_max) off[k + 1] = b0 + 4 * w + j + 1; ++k; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_found = blk_off[nb];
+}
+
 // one lane per seed occurrence: rank -> text position by LF-walk + sample (row a7), then the
 // contig test of mem_chain (bns_intv2rid; occurrences bridging contigs or strands are dropped)
 __global__ void k_sa(DevIndex ix, MemOpt opt, TileView tv, int64_t n_occ)
@@ -494,6 +593,21 @@ void launch_build_occ64(hipStream_t st, const uint32_t* bwt, uint64_t n_blocks, 
     hipLaunchKernelGGL(k_build_occ64, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, bwt, n_blocks, occ);
 }
 
+// packed reference -> one base code (0..3) per byte (bench / tooling: reads sampled from an existing image)
+__global__ void k_unpack_pac(const uint8_t* pac, int64_t start, int64_t n, uint8_t* dst)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = (uint8_t)pac_base(pac, start + i);
+}
+void launch_unpack_pac(hipStream_t st, const DevIndex& ix, int64_t start, int64_t n, uint8_t* dst)
+{
+    if (n <= 0) return;
+    int64_t nb = (n + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    hipLaunchKernelGGL(k_unpack_pac, dim3((unsigned)nb), dim3(256), 0, st, ix.pac, start, n, dst);
+}
+
 void launch_encode(hipStream_t st, uint8_t* seq, int64_t n_bytes)
 {
     if (n_bytes <= 0) return;
@@ -506,8 +620,7 @@ void launch_encode(hipStream_t st, uint8_t* seq, int64_t n_bytes)
 void launch_seed(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv)
 {
     if (tv.n_reads <= 0) return;
-    static int n_cu = 0;
-    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
+    const int n_cu = ix.n_cu > 0 ? ix.n_cu : 256;
     int K = 16, wpc = 0, refill_min = 4;
     { const char* e = getenv("BWAMEM_HIP_SEED_REFILL"); if (e && atoi(e) > 0) refill_min = atoi(e); }
     { const char* e = getenv("BWAMEM_HIP_SEED_K"); if (e && atoi(e) > 0) K = atoi(e); }
@@ -526,9 +639,33 @@ void launch_seed(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const Ti
     else hipLaunchKernelGGL(k_seed<false>, dim3(grid), dim3(64), lds, st, ix, opt, tv, K, refill_min, narrow);
     hipLaunchKernelGGL(k_seed_fin, dim3((tv.n_reads + 255) / 256), dim3(256), 0, st, opt, tv);
 }
-void launch_scan(hipStream_t st, const int32_t* in, int64_t* out, int n)
+size_t scan_tmp_bytes(int64_t n) { return (size_t)((n + 4095) / 4096 + 2) * 8; }
+// exclusive scan int32 -> int64, out[n] = total.  Short arrays: the one-workgroup kernel.  Longer ones in three small
+// launches over 4096-element blocks (block sums, scan of the sums, block-local scan + offset), so that no stage of a tile
+// waits on one workgroup sharing its CU with other tiles' kernels.  tmp: scan_tmp_bytes(n) bytes.
+void launch_scan(hipStream_t st, const int32_t* in, int64_t* out, int n, int64_t* tmp)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, in, out, n);
+    if (n <= 8192 || !tmp) { hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, in, out, n); return; }
+    const int nb = (n + 4095) / 4096;
+    hipLaunchKernelGGL(k_scan_part, dim3(nb), dim3(256), 0, st, in, n, tmp);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, tmp, nb, out + n);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, in, n, (const int64_t*)tmp, out);
+}
+size_t nul_tmp_bytes(int64_t n_bytes) { const size_t nb = (size_t)((n_bytes + 15) / 4096 + 2); return nb * 4 + 128 + (nb + 1) * 8 + scan_tmp_bytes((int64_t)nb); }
+// Offsets of the NUL-terminated reads of a stretch of the request (the job of the strlen walk at jnibwa.c:204-212, done
+// where the bytes already are): off[0] = 0, off[k + 1] = position after the k-th NUL.  n_reads_max bounds the writes;
+// *n_found (device) receives the number of NULs seen.  tmp: nul_tmp_bytes(n_bytes) bytes.
+void launch_nul_offsets(hipStream_t st, const uint8_t* seq, int64_t n_bytes, int64_t* off, int64_t n_reads_max, int64_t* n_found, void* tmp)
+{
+    const int nb = (int)((n_bytes + 4095) / 4096);
+    int32_t* cnt = (int32_t*)tmp;
+    int64_t* blk_off = (int64_t*)((char*)tmp + (((size_t)(nb + 2) * 4 + 63) & ~(size_t)63));
+    int64_t* scan_tmp = blk_off + nb + 1;
+    (void)hipMemsetAsync(off, 0, 8, st);
+    if (nb <= 0) { (void)hipMemsetAsync(n_found, 0, 8, st); return; }
+    hipLaunchKernelGGL(k_nul_count, dim3(nb), dim3(256), 0, st, seq, n_bytes, cnt);
+    launch_scan(st, cnt, blk_off, nb, scan_tmp);
+    hipLaunchKernelGGL(k_nul_write, dim3(nb), dim3(256), 0, st, seq, n_bytes, (const int64_t*)blk_off, nb, off, n_reads_max, n_found);
 }
 void launch_sa(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, int64_t n_occ)
 {

@@ -7,8 +7,12 @@ void launch_build_occ64(hipStream_t st, const uint32_t* bwt, uint64_t n_blocks, 
 // suffix array at every ix.sa_intv-th rank (lo/hi, (seq_len >> sa_shift) + 1 entries) from the image's sampling; *err: device int, OR-ed on failure
 void launch_sa_densify(hipStream_t st, const DevIndex& ix, const uint64_t* sa_src, uint64_t n_src, int src_intv, uint32_t* lo, uint8_t* hi, int32_t* err);
 void launch_encode(hipStream_t st, uint8_t* seq, int64_t n_bytes);
+void launch_unpack_pac(hipStream_t st, const DevIndex& ix, int64_t start, int64_t n, uint8_t* dst);
 void launch_seed(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
-void launch_scan(hipStream_t st, const int32_t* in, int64_t* out, int n);
+size_t scan_tmp_bytes(int64_t n);
+void launch_scan(hipStream_t st, const int32_t* in, int64_t* out, int n, int64_t* tmp);   // tmp: scan_tmp_bytes(n), or null (one-workgroup form)
+size_t nul_tmp_bytes(int64_t n_bytes);
+void launch_nul_offsets(hipStream_t st, const uint8_t* seq, int64_t n_bytes, int64_t* off, int64_t n_reads_max, int64_t* n_found, void* tmp);
 void launch_sa(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, int64_t n_occ);
 void launch_chain(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, Chain* chain_store);
 // seed re-scoring (long reads): jobs/results sized by pe_rescue_bytes for `cap` >= the tile's seed count; first_num = 2 x n_reads ints, cnt = 1 int

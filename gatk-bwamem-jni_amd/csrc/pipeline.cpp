@@ -23,6 +23,8 @@
 #include <functional>
 #include <string>
 #include <vector>
+#include <deque>
+#include <stdexcept>
 #include <algorithm>
 #include <cmath>
 #include "bwamem_types.h"
@@ -65,10 +67,9 @@ struct Timed { KernelId id; hipEvent_t a, b; };
 // Do the DP rows of the general extension / global-alignment forms fit a CU's LDS for reads of L bases (13 bytes per base:
 // up to about 12 000 bases with 160 KB)?  If not they live in global memory (k_extend<true>, k_gcigar<true>).
 // BWAMEM_HIP_DP_ROWS=hbm forces that path (tests).
-static bool dp_rows_in_hbm(int L)
+static bool dp_rows_in_hbm(int lds, int L)
 {
-    static int lds = 0;
-    if (!lds) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || lds <= 0) lds = 64 << 10; }
+    if (lds <= 0) lds = 64 << 10;
     const char* e = getenv("BWAMEM_HIP_DP_ROWS");
     if (e && !strcmp(e, "hbm")) return true;
     return extend_lds_bytes(L) + 6144 + 64 > (size_t)lds;
@@ -84,6 +85,8 @@ struct Workspace {
     DevBuf jobs, job_out, job_cig, job_cnt, zpool;   // single-end global-alignment jobs
     int job_cap = 0, job_cig_cap = 0; size_t zpool_cap = 0;
     int out_cap_hint = 512;                           // bytes per read of the output staging slots (grown on overflow, kept across tiles)
+    int dev_lds = 0;                                  // LDS per workgroup of the device this workspace lives on
+    DevBuf scan_tmp, packed;                          // block sums of the multi-block scan; the tile's packed records on their way to the host
     DevBuf pe_dir, pe_is, pe_caps, pe_reg_off2, pe_regs2, pe_ints2, pe_vpool, pe_scratch, pe_states, pe_rescue[3];   // paired-end stages
     hipStream_t stream = nullptr;
     std::vector<Timed> timed;
@@ -95,12 +98,12 @@ struct Workspace {
         if (with_seed && !(intv.ensure(t * intv_cap * sizeof(Intv)) && n_intv.ensure(t * 4) && smem.ensure(((t + 63) / 64 * 64) * 2 * smem_cap * 16)
             && l_rep.ensure(t * 4) && n_seeds.ensure(t * 4) && intv_seed_off.ensure(t * intv_cap * 4))) return false;
         dp_rows_blocks = 0;
-        if (!with_seed && dp_rows_in_hbm(L)) {                                  // a bounded grid of workgroups, each with its own three rows (about 2 GB in all)
+        if (!with_seed && dp_rows_in_hbm(dev_lds, L)) {                                  // a bounded grid of workgroups, each with its own three rows (about 2 GB in all)
             const size_t per_block = 3 * ((size_t)L + 2) * 4;
             dp_rows_blocks = (int)std::min<size_t>(4096, std::max<size_t>(256, ((size_t)2 << 30) / per_block));
             if (!dp_rows.ensure((size_t)dp_rows_blocks * per_block)) return false;
         }
-        return seed_off.ensure((t + 1) * 8)
+        return seed_off.ensure((t + 1) * 8) && scan_tmp.ensure(scan_tmp_bytes((int64_t)t + 1))
             && n_chains.ensure(t * 4) && n_regs.ensure(t * 4) && out.ensure(t * out_cap) && out_len.ensure(t * 4)
             && out_off.ensure((t + 1) * 8) && post.ensure(t * (size_t)post_per_read) && err.ensure(64) && cnt.ensure(sizeof(DevCounters));
     }
@@ -120,7 +123,7 @@ struct Workspace {
         DevBuf* all[] = { &intv, &n_intv, &smem, &l_rep, &n_seeds, &seed_off, &intv_seed_off, &seeds, &seed_rid, &cseeds, &chains,
                           &chain_store, &n_chains, &bt_nodes, &srt, &regs, &n_regs, &out, &out_len, &out_off, &post, &err, &cnt, &dp_rows,
                           &jobs, &job_out, &job_cig, &job_cnt, &zpool, &pe_dir, &pe_is, &pe_caps, &pe_reg_off2, &pe_regs2, &pe_ints2, &pe_vpool, &pe_scratch, &pe_states,
-                          &pe_rescue[0], &pe_rescue[1], &pe_rescue[2] };
+                          &pe_rescue[0], &pe_rescue[1], &pe_rescue[2], &scan_tmp, &packed };
         for (DevBuf* b : all) b->release();
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     }
@@ -157,6 +160,24 @@ struct SeedStore {
     void release() { intv.release(); n_intv.release(); intv_seed_off.release(); n_seeds.release(); l_rep.release(); }
 };
 
+// A stretch of a request that jnibwa_createAlignments streams to the device while the first stretches are already being
+// aligned: the bases (ASCII as sent, encoded in place), the read offsets found on the device and their host copy (pinned).
+// The buffers belong to the index and are reused by the next call (calls on one index are serialised).
+struct ReqBuf {
+    DevBuf seq, off, tmp;
+    int64_t* h_off = nullptr; size_t h_cap = 0;       // hipHostMalloc
+    bool ensure_host(size_t n) {
+        if (n <= h_cap) return true;
+        if (h_off) (void)hipHostFree(h_off);
+        h_off = nullptr; h_cap = 0;
+        n += n / 8 + 64;
+        if (hipHostMalloc((void**)&h_off, n * 8, hipHostMallocDefault) != hipSuccess) { h_off = nullptr; return false; }
+        h_cap = n;
+        return true;
+    }
+    void release() { seq.release(); off.release(); tmp.release(); if (h_off) (void)hipHostFree(h_off); h_off = nullptr; h_cap = 0; }
+};
+
 struct bwaidx_s {
     uint8_t* mem = nullptr; size_t l_mem = 0; bool mmapped = false;
     HostIndex h;
@@ -169,9 +190,73 @@ struct bwaidx_s {
     std::vector<Workspace*> extra_ws;   // further tiles in flight (one stream + host thread each)
     Workspace seed_ws;                  // stream, flags and spill area of the seeding stage (single-end path)
     SeedStore seed_store[2];            // double-buffered: chunk c+1 is seeded while the tiles of chunk c run
+    std::vector<ReqBuf*> req_bufs;      // request stretches of a streamed call (jnibwa_createAlignments)
+    hipStream_t up_stream = nullptr;    // their uploads
 };
 
-struct TileOut { uint8_t* d = nullptr; size_t bytes = 0; };
+struct TileOut { uint8_t* d = nullptr; size_t bytes = 0; bool owned = false; };
+
+// Where the packed records of the tiles go.  Tiles finish out of order on their workers but the response is the
+// concatenation in read order, so a tile learns its offset once every earlier tile has announced its size.
+//   to_host (jnibwa_createAlignments): straight into the malloc'ed block Java will free, tile by tile as they finish
+//     (grown by realloc, only while no copy is in flight);
+//   otherwise (bwamem_hip_batch_*): into one device slab sized from the previous call on this batch; a tile that does
+//     not fit (or the first call, when no size is known) gets an allocation of its own.
+struct OutSink {
+    bool to_host = false;
+    std::mutex mu; std::condition_variable cv;
+    std::deque<int64_t> bytes, start;               // per tile: size (-1 = not known yet), offset in the response
+    size_t n_placed = 0; int64_t placed_end = 0;    // tiles [0, n_placed) have their offsets
+    uint64_t reads_total = 0, reads_known = 0;
+    uint8_t* h_buf = nullptr; size_t h_cap = 0; int inflight = 0;
+    DevBuf pool; size_t last_total = 0;
+    bool aborted = false;
+    void begin_call(uint64_t n_reads) {
+        std::lock_guard<std::mutex> lk(mu);
+        bytes.clear(); start.clear(); n_placed = 0; placed_end = 0; reads_total = n_reads; reads_known = 0; inflight = 0; aborted = false;
+        if (h_buf) { free(h_buf); h_buf = nullptr; } h_cap = 0;
+    }
+    void add_tiles(size_t n) { std::lock_guard<std::mutex> lk(mu); bytes.resize(bytes.size() + n, -1); start.resize(start.size() + n, 0); }
+    void abort() { { std::lock_guard<std::mutex> lk(mu); aborted = true; } cv.notify_all(); }
+    // tile i has nbytes of records: its place in the response.  Host mode: the destination, to be released with copy_done().
+    // Device mode: a slice of the slab, or null (allocate).  false: the call failed elsewhere, or out of memory.
+    bool place(size_t i, int64_t nbytes, int n_reads, uint8_t** dst) {
+        std::unique_lock<std::mutex> lk(mu);
+        bytes[i] = nbytes; reads_known += (uint64_t)n_reads;
+        cv.notify_all();
+        cv.wait(lk, [&] {
+            while (n_placed < bytes.size() && bytes[n_placed] >= 0) { start[n_placed] = placed_end; placed_end += bytes[n_placed]; ++n_placed; }
+            return aborted || n_placed > i;
+        });
+        if (aborted) return false;
+        const size_t need = (size_t)(start[i] + nbytes);
+        if (!to_host) { *dst = pool.p && need <= pool.bytes ? pool.as<uint8_t>() + start[i] : nullptr; return true; }
+        if (need > h_cap) {
+            cv.wait(lk, [&] { return aborted || inflight == 0; });
+            if (aborted) return false;
+            if (need > h_cap) {
+                size_t est = reads_known ? (size_t)((double)placed_end / (double)reads_known * (double)reads_total * 1.25) : 0;
+                size_t cap = std::max(std::max(need, est), h_cap + h_cap / 2) + ((size_t)1 << 20);
+                uint8_t* nb = (uint8_t*)realloc(h_buf, cap);
+                if (!nb) { aborted = true; cv.notify_all(); return false; }
+                h_buf = nb; h_cap = cap;
+            }
+        }
+        ++inflight;
+        *dst = h_buf + start[i];
+        return true;
+    }
+    void copy_done() { { std::lock_guard<std::mutex> lk(mu); --inflight; } cv.notify_all(); }
+    // the finished response (host mode): shrunk to its size; the caller owns it
+    void* take(size_t total) {
+        std::lock_guard<std::mutex> lk(mu);
+        void* r = h_buf ? realloc(h_buf, total ? total : 1) : malloc(total ? total : 1);
+        if (!r) r = h_buf;
+        h_buf = nullptr; h_cap = 0;
+        return r;
+    }
+    ~OutSink() { if (h_buf) free(h_buf); }
+};
 
 struct bwamem_batch_s {
     bwaidx_s* idx = nullptr;
@@ -179,7 +264,9 @@ struct bwamem_batch_s {
     size_t n_bytes = 0;
     DevBuf d_raw, d_seq, d_off;     // d_raw: the request as uploaded (ASCII); d_seq: working copy, encoded per call
     std::vector<int64_t> h_off;
-    std::vector<TileOut> tiles;
+    const char* h_payload = nullptr; // streamed form (jnibwa_createAlignments): the caller's strings, uploaded stretch by stretch during the call
+    std::deque<TileOut> tiles;
+    OutSink sink;
     size_t result_bytes = 0;
     struct PeCall* pe = nullptr;    // paired-end call split in two steps (bwamem_hip_batch_pe_begin / _finish): phase-1 products kept in HBM
 };
@@ -232,6 +319,11 @@ static bool upload_index(bwaidx_s* ix)
     d.ann_name_off = ix->d_name_off.as<int32_t>(); d.names = ix->d_names.as<char>(); d.log_tab = ix->d_log.as<double>();
     d.primary = h.primary; for (int i = 0; i < 5; ++i) d.L2[i] = h.L2[i];
     d.seq_len = h.seq_len; d.l_pac = h.l_pac; d.n_seqs = n; d.log_tab_n = LOG_TAB_N;
+    {   // launch geometry of THIS device (a process may open indexes on different GPUs)
+        int v = 0;
+        d.n_cu = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ix->device) == hipSuccess && v > 0 ? v : 256;
+        d.lds_bytes = hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ix->device) == hipSuccess && v > 0 ? v : 64 << 10;
+    }
     {   // suffix array: the image samples every h.sa_intv-th rank; keep it as dense as HBM comfortably allows (5 bytes per
         // kept rank, at most a quarter of what is free now), so that a lookup is a short LF-walk or none at all
         int dense = 1;
@@ -267,6 +359,9 @@ static void free_index(bwaidx_s* ix)
     ix->seed_store[0].release(); ix->seed_store[1].release();
     for (Workspace* w : ix->extra_ws) { w->release(); delete w; }
     ix->extra_ws.clear();
+    for (ReqBuf* r : ix->req_bufs) { r->release(); delete r; }
+    ix->req_bufs.clear();
+    if (ix->up_stream) { (void)hipStreamDestroy(ix->up_stream); ix->up_stream = nullptr; }
 }
 
 // ------------------------------------------------------------------------------------------ timing
@@ -469,40 +564,50 @@ static bool build_pair_tab(bwaidx_s* ix, const MemPestat* pes)
     return true;
 }
 
-struct TileSpec { uint32_t r0, r1; int L; };
+// a tile: reads [r0, r1) of the call; seq / seq_off: device pointers to the bases of the stretch the tile lies in and to
+// the tile's r1 - r0 + 1 read offsets into it
+struct TileSpec { uint32_t r0, r1; int L; uint8_t* seq; const int64_t* seq_off; };
 
-// cut the batch into tiles from a per-workspace device-memory budget (pairs are never split when even = true)
-static std::vector<TileSpec> plan_tiles(const bwamem_batch_s* b, const MemOpt& opt, bool even, bool with_traceback)
+// a stretch of the request resident in HBM: whole reads [r0, r1), offsets relative to seq (host and device copies)
+struct ReqChunk { uint32_t r0 = 0, r1 = 0; uint8_t* seq = nullptr; const int64_t* d_off = nullptr; const int64_t* h_off = nullptr; };
+
+static uint32_t max_tile_reads(bool even)
 {
     const char* env_t = getenv("BWAMEM_HIP_TILE");
+    uint32_t max_T = env_t && atoi(env_t) > 0 ? (uint32_t)atoi(env_t) : 393216u;
+    if (even) max_T = std::max(2u, max_T & ~1u);
+    return max_T;
+}
+
+// cut a stretch of the request into tiles from a per-workspace device-memory budget (pairs are never split when even = true)
+static void plan_tiles(const ReqChunk& rc, const MemOpt& opt, bool even, bool with_traceback, std::vector<TileSpec>& tiles)
+{
     const char* env_gb = getenv("BWAMEM_HIP_TILE_GB");
     const int64_t budget = (int64_t)(env_gb ? atoi(env_gb) : 24) << 30;
-    uint32_t max_T = env_t ? (uint32_t)atoi(env_t) : 393216u;
-    if (even) max_T = std::max(2u, max_T & ~1u);
-    std::vector<TileSpec> tiles;
+    const uint32_t max_T = max_tile_reads(even);
+    const uint32_t n = rc.r1 - rc.r0;
     uint32_t r0 = 0;
-    while (r0 < b->n_reads) {
+    while (r0 < n) {
         int L0 = 1;
         uint32_t r1 = r0;
-        while (r1 < b->n_reads && r1 - r0 < max_T) {
-            int len = (int)(b->h_off[r1 + 1] - b->h_off[r1] - 1);
+        while (r1 < n && r1 - r0 < max_T) {
+            int len = (int)(rc.h_off[r1 + 1] - rc.h_off[r1] - 1);
             int L1 = std::max(L0, len);
             int64_t pr = (int64_t)std::max(64, L1 + 8) * (sizeof(Intv) + 4) + 2 * (int64_t)(L1 + 2) * 16 + 512 + post_bytes_per_read(L1, opt, with_traceback) + 64 * 300;
             if (r1 > r0 + (even ? 1u : 0u) && pr * (int64_t)(r1 - r0 + 1) > budget && (!even || ((r1 - r0) & 1) == 0)) break;
             L0 = L1; ++r1;
         }
-        TileSpec t; t.r0 = r0; t.r1 = r1; t.L = L0;
+        TileSpec t; t.r0 = rc.r0 + r0; t.r1 = rc.r0 + r1; t.L = L0; t.seq = rc.seq; t.seq_off = rc.d_off + r0;
         tiles.push_back(t);
         r0 = r1;
     }
-    return tiles;
 }
 
-// The seeding stage of the single-end path: k_seed + k_seed_fin over one chunk of reads (several tiles), on the seeding
-// workspace's stream, into one of the two interval stores.
-struct SeedChunk { uint32_t r0 = 0, r1 = 0; int L = 1; size_t tile0 = 0, tile1 = 0; int state = 0; size_t tiles_left = 0; };   // state: 0 pending, 1 ready, -1 failed
+// The seeding stage: k_seed + k_seed_fin over one chunk of reads (several tiles), on the seeding workspace's stream, into
+// one of the two interval stores.
+struct SeedChunk { uint32_t r0 = 0, r1 = 0; int L = 1; uint8_t* seq = nullptr; const int64_t* seq_off = nullptr; size_t tile0 = 0, tile1 = 0; int state = 0; size_t tiles_left = 0; };   // state: 0 pending, 1 ready, -1 failed
 
-static bool seed_chunk(bwaidx_s* ix, const MemOpt& opt, bwamem_batch_s* b, const SeedChunk& ch, SeedStore& store, int& intv_cap_scale)
+static bool seed_chunk(bwaidx_s* ix, const MemOpt& opt, const SeedChunk& ch, SeedStore& store, int& intv_cap_scale)
 {
     Workspace& sw = ix->seed_ws;
     if (!sw.stream) {
@@ -523,7 +628,7 @@ static bool seed_chunk(bwaidx_s* ix, const MemOpt& opt, bwamem_batch_s* b, const
         if (!sw.err.ensure(64) || !sw.cnt.ensure(sizeof(DevCounters)) || !sw.smem.ensure((size_t)groups * (L + 2) * 64 * 16)) return false;
         TileView tv; memset(&tv, 0, sizeof tv);
         tv.n_reads = T; tv.max_len = L;
-        tv.seq = b->d_seq.as<uint8_t>(); tv.seq_off = b->d_off.as<int64_t>() + ch.r0;
+        tv.seq = ch.seq; tv.seq_off = ch.seq_off;
         tv.intv_cap = cap; tv.intv = store.intv.as<Intv>(); tv.n_intv = store.n_intv.as<int32_t>();
         tv.intv_seed_off = store.intv_seed_off.as<int32_t>(); tv.n_seeds = store.n_seeds.as<int32_t>(); tv.l_rep = store.l_rep.as<int32_t>();
         tv.smem_scratch = sw.smem.as<Intv>(); tv.smem_cap = L + 2; tv.smem_groups = groups;
@@ -544,8 +649,57 @@ static bool seed_chunk(bwaidx_s* ix, const MemOpt& opt, bwamem_batch_s* b, const
     return false;
 }
 
+// a tile's view of its reads and of its slice of the chunk's interval lists
+static TileView tile_view(const Workspace& ws, const TileSpec& spec, int64_t read_id0, const SeedStore& seeds_of_chunk, uint32_t chunk_r0)
+{
+    TileView v = ws.view();
+    v.n_reads = (int)(spec.r1 - spec.r0); v.max_len = spec.L; v.read_id0 = read_id0 + spec.r0;
+    v.seq = spec.seq; v.seq_off = spec.seq_off;
+    const size_t at = (size_t)(spec.r0 - chunk_r0);
+    v.intv_cap = seeds_of_chunk.cap;
+    v.intv = seeds_of_chunk.intv.as<Intv>() + at * seeds_of_chunk.cap;
+    v.intv_seed_off = seeds_of_chunk.intv_seed_off.as<int32_t>() + at * seeds_of_chunk.cap;
+    v.n_intv = seeds_of_chunk.n_intv.as<int32_t>() + at;
+    v.n_seeds = seeds_of_chunk.n_seeds.as<int32_t>() + at;
+    v.l_rep = seeds_of_chunk.l_rep.as<int32_t>() + at;
+    v.smem_scratch = nullptr; v.smem_groups = 0;
+    return v;
+}
+
+// the packed records of a finished tile: into the response (host mode: copied out now, from the workspace's packing
+// buffer) or into the batch's device slab
+static bool emit_tile(Workspace& ws, bwamem_batch_s* b, size_t tile_index, const TileView& tv, int64_t out_total, TileOut& to)
+{
+    OutSink& sink = b->sink;
+    uint8_t* dst = nullptr;
+    to.bytes = (size_t)out_total; to.d = nullptr; to.owned = false;
+    if (!sink.place(tile_index, out_total, tv.n_reads, &dst)) return false;
+    if (sink.to_host) {
+        bool ok = true;
+        if (out_total > 0) {
+            ok = ws.packed.ensure((size_t)out_total);
+            if (ok) {
+                timed_begin(ws, K_PACK); launch_pack(ws.stream, tv, ws.packed.as<uint8_t>()); timed_end(ws);
+                ok = hipGetLastError() == hipSuccess
+                  && hipMemcpyAsync(dst, ws.packed.p, (size_t)out_total, hipMemcpyDeviceToHost, ws.stream) == hipSuccess
+                  && hipStreamSynchronize(ws.stream) == hipSuccess;
+            }
+        }
+        sink.copy_done();
+        if (!ok) fprintf(stderr, "[bwamem_hip] response download failed\n");
+        return ok;
+    }
+    if (out_total > 0) {
+        if (dst) to.d = dst;
+        else { HIP_OK(hipMalloc((void**)&to.d, (size_t)out_total)); to.owned = true; }
+        TIMED(ws, K_PACK, launch_pack(ws.stream, tv, to.d));
+        HIP_OK(hipStreamSynchronize(ws.stream));
+    }
+    return true;
+}
+
 // one single-end tile, start to packed response, on the workspace's own stream
-static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_batch_s* b, int64_t read_id0, const TileSpec& spec,
+static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_batch_s* b, int64_t read_id0, size_t tile_index, const TileSpec& spec,
                         TileOut& to, const SeedStore& seeds_of_chunk, uint32_t chunk_r0, int& out_cap)
 {
     const uint32_t r0 = spec.r0;
@@ -560,39 +714,25 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
             const int jc = std::max(job_cap_hint, std::max(1024, T / 4));
             if (!ws.ensure_jobs(jc, 4 * L + 16, std::max(zpool_hint, (size_t)jc * (size_t)(2 * L + 64) * 20 + ((size_t)64 << 20)))) return false;
         }
-        auto make_view = [&]() {
-            TileView v = ws.view();
-            v.n_reads = T; v.max_len = L; v.read_id0 = read_id0 + r0;
-            v.seq = b->d_seq.as<uint8_t>(); v.seq_off = b->d_off.as<int64_t>() + r0;
-            const size_t at = (size_t)(r0 - chunk_r0);              // this tile's slice of the chunk's interval lists
-            v.intv_cap = seeds_of_chunk.cap;
-            v.intv = seeds_of_chunk.intv.as<Intv>() + at * seeds_of_chunk.cap;
-            v.intv_seed_off = seeds_of_chunk.intv_seed_off.as<int32_t>() + at * seeds_of_chunk.cap;
-            v.n_intv = seeds_of_chunk.n_intv.as<int32_t>() + at;
-            v.n_seeds = seeds_of_chunk.n_seeds.as<int32_t>() + at;
-            v.l_rep = seeds_of_chunk.l_rep.as<int32_t>() + at;
-            v.smem_scratch = nullptr; v.smem_groups = 0;
-            return v;
-        };
-        TileView tv = make_view();
+        TileView tv = tile_view(ws, spec, read_id0, seeds_of_chunk, chunk_r0);
         HIP_OK(hipMemsetAsync(ws.err.p, 0, 64, ws.stream));
         HIP_OK(hipMemsetAsync(ws.cnt.p, 0, sizeof(DevCounters), ws.stream));
         HIP_OK(hipMemsetAsync(ws.job_cnt.p, 0, 64, ws.stream));
-        TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_seeds, tv.seed_off, T));
+        TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_seeds, tv.seed_off, T, ws.scan_tmp.as<int64_t>()));
         int64_t n_occ = 0; int32_t err = 0; int32_t errv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIP_OK(hipMemcpyAsync(&n_occ, tv.seed_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
         HIP_OK(hipStreamSynchronize(ws.stream));
         if (n_occ > ws.seed_cap) {
             if (!ws.ensure_seeds(n_occ + n_occ / 4)) return false;
-            tv = make_view();
+            tv = tile_view(ws, spec, read_id0, seeds_of_chunk, chunk_r0);
         }
         TIMED(ws, K_SA, launch_sa(ws.stream, ix->d, opt, tv, n_occ));
         TIMED(ws, K_CHAIN, launch_chain(ws.stream, ix->d, opt, tv, ws.chain_store.as<Chain>()));
         if (rescore_needed(opt, tv)) {                     // long reads: seed re-scoring jobs (at most one per seed occurrence)
-        const int rc = (int)std::min<int64_t>(n_occ + 16, 0x7fffffff);
-        if (!(ws.pe_rescue[0].ensure(pe_rescue_bytes(0, rc)) && ws.pe_rescue[1].ensure(pe_rescue_bytes(1, rc)) && ws.pe_rescue[2].ensure((size_t)T * 8 + 64))) return false;
-        TIMED(ws, K_CHAIN, launch_rescore(ws.stream, ix->d, opt, tv, ws.pe_rescue[0].p, ws.pe_rescue[1].p, ws.pe_rescue[2].as<int32_t>() + 16, ws.pe_rescue[2].as<int32_t>(), rc));
-    }
+            const int rc = (int)std::min<int64_t>(n_occ + 16, 0x7fffffff);
+            if (!(ws.pe_rescue[0].ensure(pe_rescue_bytes(0, rc)) && ws.pe_rescue[1].ensure(pe_rescue_bytes(1, rc)) && ws.pe_rescue[2].ensure((size_t)T * 8 + 64))) return false;
+            TIMED(ws, K_CHAIN, launch_rescore(ws.stream, ix->d, opt, tv, ws.pe_rescue[0].p, ws.pe_rescue[1].p, ws.pe_rescue[2].as<int32_t>() + 16, ws.pe_rescue[2].as<int32_t>(), rc));
+        }
         TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
         if (getenv("BWAMEM_HIP_DUMP") && T <= 64) debug_dump(ws, tv, T);
         TIMED(ws, K_POST, launch_post1(ws.stream, ix->d, opt, tv));
@@ -604,7 +744,7 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
         TIMED(ws, K_FINAL, launch_gcigar(ws.stream, ix->d, opt, tv, n_jobs, ws.jobs.p, ws.job_out.p, ws.job_cig.as<uint32_t>(), ws.job_cig_cap,
                                          ws.zpool.as<uint8_t>(), (unsigned long long)ws.zpool_cap, (unsigned long long*)(ws.job_cnt.as<int32_t>() + 2)));
         TIMED(ws, K_FINAL, launch_final_se(ws.stream, ix->d, opt, tv, ws.job_out.p, ws.job_cig.as<uint32_t>(), ws.job_cig_cap));
-        TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.out_len, tv.out_off, T));
+        TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.out_len, tv.out_off, T, ws.scan_tmp.as<int64_t>()));
         int64_t out_total = 0;
         DevCounters hc;
         HIP_OK(hipMemcpyAsync(&out_total, tv.out_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
@@ -623,12 +763,7 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
             if (err & ERR_JOB_CAP) { job_cap_hint = std::max(ws.job_cap * 2, 4096); continue; }
             fprintf(stderr, "[bwamem_hip] device error flags %d\n", err); return false;
         }
-        to.bytes = (size_t)out_total; to.d = nullptr;
-        if (out_total > 0) {
-            HIP_OK(hipMalloc((void**)&to.d, (size_t)out_total));
-            TIMED(ws, K_PACK, launch_pack(ws.stream, tv, to.d));
-            HIP_OK(hipStreamSynchronize(ws.stream));
-        }
+        if (!emit_tile(ws, b, tile_index, tv, out_total, to)) return false;
         {
             std::lock_guard<std::mutex> lk(g_stats.mu);
             g_stats.s.n_reads += T; g_stats.s.n_ext += hc.n_ext; g_stats.s.n_lf += hc.n_lf; g_stats.s.n_sa += hc.n_sa;
@@ -639,93 +774,221 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
     }
 }
 
-// Runs fn for every tile on worker threads (one stream + workspace each, BWAMEM_HIP_STREAMS of them), with the seeding
-// stage one chunk of tiles ahead on its own stream: fn finds the interval lists of its tile in the store it is handed
+// ---------------------------------------------------------------------------------------- the call pipeline
+// Three kinds of host threads share one call: a PRODUCER makes stretches of the request resident (all at once for a
+// batch that already lives in HBM; for jnibwa_createAlignments by streaming the caller's buffer to the device while the
+// first stretches are being aligned) and cuts them into tiles and seeding chunks; the SEEDER runs k_seed one chunk ahead
+// of the tiles; WORKERS (one stream + workspace each, BWAMEM_HIP_STREAMS of them) take the tiles in order.
+struct CallPipe {
+    std::mutex mu; std::condition_variable cv;
+    std::deque<TileSpec> specs; std::deque<SeedChunk> chunks; std::deque<size_t> chunk_of;
+    bool produced_all = false, failed = false;
+    size_t next_tile = 0;
+    std::function<void(size_t)> on_new_tiles;        // called (under mu) with the number of tiles just appended
+    void fail() { { std::lock_guard<std::mutex> lk(mu); failed = true; } cv.notify_all(); }
+};
+
+// Seeding chunks: runs of consecutive tiles.  k_seed cannot finish before its slowest read has (one lane walks one read),
+// so a launch over one tile spends much of its time in a thin tail; over a few million reads the queue keeps the lanes fed
+// for most of the launch.  The first chunks are small (one tile, then two, ...) so that the tile workers start early.
+static void append_stretch(CallPipe& pp, const ReqChunk& rc, const MemOpt& opt, bool even)
+{
+    std::vector<TileSpec> tiles;
+    plan_tiles(rc, opt, even, false, tiles);
+    const char* e = getenv("BWAMEM_HIP_SEED_CHUNK");
+    const uint32_t chunk_reads = e && atoi(e) > 0 ? (uint32_t)atoi(e) : 2097152u;
+    const char* eg = getenv("BWAMEM_HIP_SEED_GB");
+    const int64_t budget = (int64_t)(eg && atoi(eg) > 0 ? atoi(eg) : 16) << 30;     // per interval store
+    std::lock_guard<std::mutex> lk(pp.mu);
+    bool fresh = true;                                                               // a chunk never spans two stretches (separate buffers)
+    for (const TileSpec& t : tiles) {
+        const size_t i = pp.specs.size();
+        const int64_t n_new = fresh ? 0 : (int64_t)(t.r1 - pp.chunks.back().r0);
+        const int L_new = fresh ? 1 : std::max(pp.chunks.back().L, t.L);
+        const int64_t first_T = (int64_t)(pp.specs.empty() ? t.r1 - t.r0 : pp.specs[0].r1 - pp.specs[0].r0);
+        const int64_t ramp = std::min<int64_t>((int64_t)chunk_reads, first_T << std::min<size_t>(pp.chunks.empty() ? 0 : pp.chunks.size() - (fresh ? 0 : 1), 8));
+        if (fresh || n_new > ramp || n_new * std::max(64, L_new + 8) * 36 > budget) {
+            SeedChunk c; c.r0 = t.r0; c.tile0 = i; c.L = 1; c.seq = t.seq; c.seq_off = t.seq_off;
+            pp.chunks.push_back(c);
+            fresh = false;
+        }
+        SeedChunk& c = pp.chunks.back();
+        c.r1 = t.r1; c.tile1 = i + 1; c.L = std::max(c.L, t.L); c.tiles_left = c.tile1 - c.tile0;
+        pp.specs.push_back(t);
+        pp.chunk_of.push_back(pp.chunks.size() - 1);
+    }
+    if (pp.on_new_tiles) pp.on_new_tiles(tiles.size());
+    pp.cv.notify_all();
+}
+
+// number of NUL bytes in [p, p + n)
+static size_t count_zero_bytes(const char* p, size_t n) { size_t c = 0; for (size_t i = 0; i < n; ++i) c += p[i] == 0; return c; }
+
+// The end (exclusive, right after a NUL) of the stretch of the request starting at p that holds `want` reads, or fewer once
+// it is max_bytes long; *got = the reads in it.  The request carries no length (jnibwa.c:204-212 walks it with strlen), so
+// this walk is what bounds every access to the caller's buffer.  It counts NULs a page at a time: the bytes up to the end
+// of the page p points into are readable whenever p itself is inside the request (the classic strlen argument).
+static const char* scan_reads(const char* p0, uint64_t want, size_t max_bytes, uint64_t* got)
+{
+    const char* q = p0;
+    uint64_t have = 0;
+#if defined(__SANITIZE_ADDRESS__) || defined(BWAMEM_HIP_EXACT_WALK)
+    while (have < want) { q += strlen(q) + 1; ++have; if ((size_t)(q - p0) >= max_bytes) break; }
+#else
+    while (have < want) {
+        const size_t n = 4096 - ((uintptr_t)q & 4095);
+        const size_t c = count_zero_bytes(q, n);
+        if (have + c < want && (size_t)(q + n - p0) < max_bytes) { have += c; q += n; continue; }
+        const char* e = q + n;
+        bool done = false;
+        while (q < e) {                                           // the stop lies in this page (or the page has no NUL at all)
+            const char* z = (const char*)memchr(q, 0, (size_t)(e - q));
+            if (!z) { q = e; break; }
+            q = z + 1; ++have;
+            if (have == want || (size_t)(q - p0) >= max_bytes) { done = true; break; }
+        }
+        if (done) break;
+    }
+#endif
+    *got = have;
+    return q;
+}
+
+// producer of a streamed call: walk, upload, find the read offsets on the device, encode -- stretch by stretch
+static bool produce_streamed(bwaidx_s* ix, CallPipe& pp, bwamem_batch_s* b, const MemOpt& opt, bool even)
+{
+    HIP_OK(hipSetDevice(ix->device));
+    if (!ix->up_stream) HIP_OK(hipStreamCreateWithFlags(&ix->up_stream, hipStreamNonBlocking));
+    hipStream_t st = ix->up_stream;
+    const uint32_t max_T = max_tile_reads(even);
+    const char* e = getenv("BWAMEM_HIP_SEED_CHUNK");
+    const uint64_t chunk_reads = e && atoi(e) > 0 ? (uint64_t)atoi(e) : 2097152u;
+    const char* eb = getenv("BWAMEM_HIP_UPLOAD_BYTES");
+    const size_t max_bytes = eb && atoll(eb) > 0 ? (size_t)atoll(eb) : (size_t)384 << 20;
+    const char* p = b->h_payload;
+    uint64_t r = 0;
+    size_t k = 0;
+    while (r < b->n_reads) {
+        { std::lock_guard<std::mutex> lk(pp.mu); if (pp.failed) return false; }
+        uint64_t want = std::min<uint64_t>(chunk_reads, (uint64_t)max_T << std::min<size_t>(k, 8));
+        want = std::min<uint64_t>(std::max<uint64_t>(want, even ? 2 : 1), b->n_reads - r);
+        if (even && (want & 1) && r + want < b->n_reads) ++want;
+        uint64_t got = 0;
+        const char* end = scan_reads(p, want, max_bytes, &got);
+        if (even && (got & 1) && r + got < b->n_reads) { uint64_t one = 0; end = scan_reads(end, 1, (size_t)-1, &one); got += one; }   // a pair is never split
+        const size_t nbytes = (size_t)(end - p);
+        if (nbytes >= ((size_t)1 << 40)) { fprintf(stderr, "[bwamem_hip] request stretch too large\n"); return false; }
+        if (k >= ix->req_bufs.size()) ix->req_bufs.push_back(new ReqBuf());
+        ReqBuf& rb = *ix->req_bufs[k];
+        if (!rb.seq.ensure(nbytes + 64) || !rb.off.ensure((got + 2) * 8 + 16) || !rb.tmp.ensure(nul_tmp_bytes((int64_t)nbytes)) || !rb.ensure_host(got + 2)) return false;
+        int64_t* d_found = rb.off.as<int64_t>() + got + 1;           // one spare slot behind the offsets
+        HIP_OK(hipMemcpyAsync(rb.seq.p, p, nbytes, hipMemcpyHostToDevice, st));
+        launch_nul_offsets(st, rb.seq.as<uint8_t>(), (int64_t)nbytes, rb.off.as<int64_t>(), (int64_t)got, d_found, rb.tmp.p);
+        launch_encode(st, rb.seq.as<uint8_t>(), (int64_t)nbytes);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpyAsync(rb.h_off, rb.off.p, (got + 2) * 8, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        if (rb.h_off[got + 1] != (int64_t)got || rb.h_off[got] != (int64_t)nbytes) {
+            fprintf(stderr, "[bwamem_hip] internal error: device read offsets disagree with the host walk (%lld reads / %lld bytes against %llu / %zu)\n",
+                    (long long)rb.h_off[got + 1], (long long)rb.h_off[got], (unsigned long long)got, nbytes);
+            return false;
+        }
+        ReqChunk rc; rc.r0 = (uint32_t)r; rc.r1 = (uint32_t)(r + got); rc.seq = rb.seq.as<uint8_t>(); rc.d_off = rb.off.as<int64_t>(); rc.h_off = rb.h_off;
+        append_stretch(pp, rc, opt, even);
+        b->n_bytes += nbytes;
+        p = end; r += got; ++k;
+    }
+    return true;
+}
+
+// Runs fn for every tile of the call (see CallPipe).  fn finds the interval lists of its tile in the store it is handed
 // (at offset r0 - chunk_r0).
-typedef std::function<bool(Workspace&, size_t, const SeedStore&, uint32_t)> TileFn;
-static bool run_tiles_seeded(bwaidx_s* ix, const MemOpt& opt, bwamem_batch_s* b, const std::vector<TileSpec>& specs, const TileFn& fn)
+typedef std::function<bool(Workspace&, size_t, const TileSpec&, const SeedStore&, uint32_t)> TileFn;
+static bool run_pipeline(bwaidx_s* ix, const MemOpt& opt, bwamem_batch_s* b, bool even, CallPipe& pp, const TileFn& fn)
 {
     const char* env_s = getenv("BWAMEM_HIP_STREAMS");
-    int n_workers = std::max(1, std::min<int>((int)specs.size(), env_s ? atoi(env_s) : 4));
+    const int n_workers = std::max(1, env_s ? atoi(env_s) : 4);
     while ((int)ix->extra_ws.size() < n_workers - 1) ix->extra_ws.push_back(new Workspace());
-
-    // Seeding chunks: runs of consecutive tiles.  k_seed cannot finish before its slowest read has (one lane walks one
-    // read), so a launch over one tile spends much of its time in a thin tail; over a few million reads the queue keeps
-    // the lanes fed for most of the launch.  A seeding thread stays one chunk ahead of the tile workers (two interval
-    // stores); BWAMEM_HIP_SEED_AHEAD=0 serialises it behind the tiles (isolated kernel timings).
-    std::vector<SeedChunk> chunks;
-    {
-        const char* e = getenv("BWAMEM_HIP_SEED_CHUNK");
-        const uint32_t chunk_reads = e && atoi(e) > 0 ? (uint32_t)atoi(e) : 2097152u;
-        const char* eg = getenv("BWAMEM_HIP_SEED_GB");
-        const int64_t budget = (int64_t)(eg && atoi(eg) > 0 ? atoi(eg) : 16) << 30;     // per interval store
-        for (size_t i = 0; i < specs.size(); ++i) {
-            const int64_t n_new = chunks.empty() ? 0 : (int64_t)(specs[i].r1 - chunks.back().r0);
-            const int L_new = chunks.empty() ? 1 : std::max(chunks.back().L, specs[i].L);
-            // the first chunks are small (one tile, then two, ...) so that the tile workers start early; the tiles behind them overlap the big ones
-            const int64_t ramp = std::min<int64_t>((int64_t)chunk_reads, (int64_t)(specs[0].r1 - specs[0].r0) << std::min<size_t>(chunks.empty() ? 0 : chunks.size() - 1, 8));
-            if (chunks.empty() || n_new > ramp || n_new * std::max(64, L_new + 8) * 36 > budget) {
-                SeedChunk c; c.r0 = specs[i].r0; c.tile0 = i; c.L = 1;
-                chunks.push_back(c);
-            }
-            SeedChunk& c = chunks.back();
-            c.r1 = specs[i].r1; c.tile1 = i + 1; c.L = std::max(c.L, specs[i].L); c.tiles_left = c.tile1 - c.tile0;
-        }
-    }
-    std::vector<size_t> chunk_of(specs.size());
-    for (size_t c = 0; c < chunks.size(); ++c) for (size_t i = chunks[c].tile0; i < chunks[c].tile1; ++i) chunk_of[i] = c;
+    // BWAMEM_HIP_SEED_AHEAD=0 serialises the seeding behind the tiles (isolated kernel timings)
     const bool seed_ahead = !(getenv("BWAMEM_HIP_SEED_AHEAD") && atoi(getenv("BWAMEM_HIP_SEED_AHEAD")) == 0);
-    std::mutex mu;
-    std::condition_variable cv;
-    std::atomic<size_t> next(0);
-    std::atomic<bool> failed(false);
-    auto seeder = [&]() {
-        if (hipSetDevice(ix->device) != hipSuccess) { failed = true; cv.notify_all(); return; }
-        int intv_cap_scale = 1;
-        for (size_t c = 0; c < chunks.size() && !failed; ++c) {
-            {   // the store of chunk c was last used by chunk c-2
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] {
-                    if (failed) return true;
-                    for (size_t k = 0; k < c; ++k) if ((k + 2 <= c || !seed_ahead) && chunks[k].tiles_left != 0) return false;
-                    return true;
-                });
+    auto fail = [&]() { pp.fail(); b->sink.abort(); };
+    auto producer = [&]() {
+        bool ok = false;
+        try {
+            if (b->h_payload) ok = produce_streamed(ix, pp, b, opt, even);
+            else {
+                ReqChunk rc; rc.r0 = 0; rc.r1 = b->n_reads; rc.seq = b->d_seq.as<uint8_t>(); rc.d_off = b->d_off.as<int64_t>(); rc.h_off = b->h_off.data();
+                append_stretch(pp, rc, opt, even);
+                ok = true;
             }
-            if (failed) break;
-            const bool ok = seed_chunk(ix, opt, b, chunks[c], ix->seed_store[c & 1], intv_cap_scale);
-            { std::lock_guard<std::mutex> lk(mu); chunks[c].state = ok ? 1 : -1; if (!ok) failed = true; }
-            cv.notify_all();
-        }
+        } catch (const std::exception& ex) { fprintf(stderr, "[bwamem_hip] %s\n", ex.what()); }
+        if (!ok) fail();
+        { std::lock_guard<std::mutex> lk(pp.mu); pp.produced_all = true; }
+        pp.cv.notify_all();
+    };
+    auto seeder = [&]() {
+        try {
+            if (hipSetDevice(ix->device) != hipSuccess) { fail(); return; }
+            int intv_cap_scale = 1;
+            for (size_t c = 0; ; ++c) {
+                SeedChunk ch;
+                {
+                    std::unique_lock<std::mutex> lk(pp.mu);
+                    pp.cv.wait(lk, [&] { return pp.failed || c < pp.chunks.size() || pp.produced_all; });
+                    if (pp.failed || c >= pp.chunks.size()) break;
+                    pp.cv.wait(lk, [&] {                                       // the store of chunk c was last used by chunk c-2
+                        if (pp.failed) return true;
+                        for (size_t k = 0; k < c; ++k) if ((k + 2 <= c || !seed_ahead) && pp.chunks[k].tiles_left != 0) return false;
+                        return true;
+                    });
+                    if (pp.failed) break;
+                    ch = pp.chunks[c];
+                }
+                const bool ok = seed_chunk(ix, opt, ch, ix->seed_store[c & 1], intv_cap_scale);
+                { std::lock_guard<std::mutex> lk(pp.mu); pp.chunks[c].state = ok ? 1 : -1; }
+                if (!ok) { fail(); break; }
+                pp.cv.notify_all();
+            }
+        } catch (const std::exception& ex) { fprintf(stderr, "[bwamem_hip] %s\n", ex.what()); fail(); }
     };
     auto worker = [&](int k) {
-        Workspace& w = k == 0 ? ix->ws : *ix->extra_ws[k - 1];
-        if (hipSetDevice(ix->device) != hipSuccess) { failed = true; cv.notify_all(); return; }
-        if (!w.stream && hipStreamCreate(&w.stream) != hipSuccess) { failed = true; cv.notify_all(); return; }
-        while (!failed) {
-            size_t i = next++;
-            if (i >= specs.size()) break;
-            const size_t c = chunk_of[i];
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return failed || chunks[c].state != 0; }); }
-            if (failed) break;
-            if (!fn(w, i, ix->seed_store[c & 1], chunks[c].r0)) failed = true;
-            { std::lock_guard<std::mutex> lk(mu); --chunks[c].tiles_left; }
-            cv.notify_all();
-        }
-        cv.notify_all();
+        try {
+            Workspace& w = k == 0 ? ix->ws : *ix->extra_ws[k - 1];
+            w.dev_lds = ix->d.lds_bytes;
+            if (hipSetDevice(ix->device) != hipSuccess) { fail(); return; }
+            if (!w.stream && hipStreamCreate(&w.stream) != hipSuccess) { fail(); return; }
+            for (;;) {
+                size_t i, c; TileSpec sp; uint32_t chunk_r0;
+                {
+                    std::unique_lock<std::mutex> lk(pp.mu);
+                    pp.cv.wait(lk, [&] { return pp.failed || pp.next_tile < pp.specs.size() || pp.produced_all; });
+                    if (pp.failed || pp.next_tile >= pp.specs.size()) break;
+                    i = pp.next_tile++; sp = pp.specs[i]; c = pp.chunk_of[i];
+                    pp.cv.wait(lk, [&] { return pp.failed || pp.chunks[c].state != 0; });
+                    if (pp.failed || pp.chunks[c].state < 0) break;
+                    chunk_r0 = pp.chunks[c].r0;
+                }
+                const bool ok = fn(w, i, sp, ix->seed_store[c & 1], chunk_r0);
+                { std::lock_guard<std::mutex> lk(pp.mu); --pp.chunks[c].tiles_left; }
+                pp.cv.notify_all();
+                if (!ok) { fail(); break; }
+            }
+        } catch (const std::exception& ex) { fprintf(stderr, "[bwamem_hip] %s\n", ex.what()); fail(); }
     };
     std::vector<std::thread> th;
+    th.emplace_back(producer);
     th.emplace_back(seeder);
     for (int k = 1; k < n_workers; ++k) th.emplace_back(worker, k);
     worker(0);
     for (std::thread& t : th) t.join();
-    return !failed;
+    return !pp.failed;
 }
 
 // ---------------------------------------------------------------------------------------- paired-end call
 // Phase 1 (per tile, tiles in flight like single-end, seeding in chunks): seeds .. regions of every read, kept per tile,
 // and the per-pair insert-size candidates.  Then the batch-global statistics on the host (mem_pestat), unless the caller
 // supplied them.  Phase 2 (per tile, tiles in flight): mate rescue, pairing, DP jobs, records.
-struct PeTile { uint32_t r0 = 0; int T = 0, L = 0; DevBuf n_regs, regs, reg_off; int64_t n_regs_total = 0; std::vector<int8_t> cand_dir; std::vector<int64_t> cand_is; };
+struct PeTile { uint32_t r0 = 0; int T = 0, L = 0; uint8_t* seq = nullptr; const int64_t* seq_off = nullptr; DevBuf n_regs, regs, reg_off; int64_t n_regs_total = 0; std::vector<int8_t> cand_dir; std::vector<int64_t> cand_is; };
 
 #define PE_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "[bwamem_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return false; } } while (0)
 #define PE_REQ(cond) do { if (!(cond)) return false; } while (0)
@@ -737,24 +1000,11 @@ static bool pe_phase1_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
     const int T = (int)(spec.r1 - spec.r0), L = spec.L;
     PE_REQ(ws.ensure_reads(T, L, seeds_of_chunk.cap, ws.out_cap_hint, post_bytes_per_read(L, opt, false), false));
     PE_REQ(ws.ensure_seeds(std::max<int64_t>(ws.seed_cap, (int64_t)T * 16)));
-    auto make_view = [&]() {
-        TileView v = ws.view();
-        v.n_reads = T; v.max_len = L; v.read_id0 = read_id0 + r0;
-        v.seq = b->d_seq.as<uint8_t>(); v.seq_off = b->d_off.as<int64_t>() + r0;
-        const size_t at = (size_t)(r0 - chunk_r0);
-        v.intv_cap = seeds_of_chunk.cap;
-        v.intv = seeds_of_chunk.intv.as<Intv>() + at * seeds_of_chunk.cap;
-        v.intv_seed_off = seeds_of_chunk.intv_seed_off.as<int32_t>() + at * seeds_of_chunk.cap;
-        v.n_intv = seeds_of_chunk.n_intv.as<int32_t>() + at;
-        v.n_seeds = seeds_of_chunk.n_seeds.as<int32_t>() + at;
-        v.l_rep = seeds_of_chunk.l_rep.as<int32_t>() + at;
-        v.smem_scratch = nullptr; v.smem_groups = 0;
-        return v;
-    };
+    auto make_view = [&]() { return tile_view(ws, spec, read_id0, seeds_of_chunk, chunk_r0); };
     TileView tv = make_view();
     PE_OK(hipMemsetAsync(ws.err.p, 0, 64, ws.stream));
     PE_OK(hipMemsetAsync(ws.cnt.p, 0, sizeof(DevCounters), ws.stream));
-    TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_seeds, tv.seed_off, T));
+    TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_seeds, tv.seed_off, T, ws.scan_tmp.as<int64_t>()));
     int64_t n_occ = 0; int32_t err = 0;
     PE_OK(hipMemcpyAsync(&n_occ, tv.seed_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
     PE_OK(hipStreamSynchronize(ws.stream));
@@ -768,9 +1018,9 @@ static bool pe_phase1_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
     }
     TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
     TIMED(ws, K_POST, launch_post1(ws.stream, ix->d, opt, tv));
-    pt->r0 = r0; pt->T = T; pt->L = L;
+    pt->r0 = r0; pt->T = T; pt->L = L; pt->seq = spec.seq; pt->seq_off = spec.seq_off;
     PE_REQ(pt->n_regs.ensure((size_t)T * 4) && pt->reg_off.ensure(((size_t)T + 1) * 8));
-    TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_regs, pt->reg_off.as<int64_t>(), T));
+    TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_regs, pt->reg_off.as<int64_t>(), T, ws.scan_tmp.as<int64_t>()));
     DevCounters hc;
     PE_OK(hipMemcpyAsync(&pt->n_regs_total, pt->reg_off.as<int64_t>() + T, 8, hipMemcpyDeviceToHost, ws.stream));
     PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
@@ -799,7 +1049,7 @@ static bool pe_phase1_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
     return true;
 }
 
-static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_batch_s* b, int64_t read_id0, PeTile* pt, const MemPestat* pes, TileOut& to)
+static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_batch_s* b, int64_t read_id0, size_t tile_index, PeTile* pt, const MemPestat* pes, TileOut& to)
 {
     const int T = pt->T, L = pt->L;
     int attempts = 0, cap_u = 256, pe_job_cap = 0, pe_rescue_cap = 0;
@@ -809,12 +1059,12 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
         PE_REQ(ws.ensure_reads(T, L, 0, ws.out_cap_hint, post_bytes_per_read(L, opt, false), false));
         TileView tv = ws.view();
         tv.n_reads = T; tv.max_len = L; tv.read_id0 = read_id0 + pt->r0;
-        tv.seq = b->d_seq.as<uint8_t>(); tv.seq_off = b->d_off.as<int64_t>() + pt->r0;
+        tv.seq = pt->seq; tv.seq_off = pt->seq_off;
         PE_OK(hipMemsetAsync(ws.err.p, 0, 64, ws.stream));
         PE_OK(hipMemcpyAsync(tv.n_regs, pt->n_regs.p, (size_t)T * 4, hipMemcpyDeviceToDevice, ws.stream));
         PE_REQ(ws.pe_caps.ensure((size_t)T * 4) && ws.pe_reg_off2.ensure(((size_t)T + 1) * 8));
         TIMED(ws, K_OTHER, launch_pe_caps(ws.stream, opt, tv, ws.pe_caps.as<int32_t>()));
-        TIMED(ws, K_OTHER, launch_scan(ws.stream, ws.pe_caps.as<int32_t>(), ws.pe_reg_off2.as<int64_t>(), T));
+        TIMED(ws, K_OTHER, launch_scan(ws.stream, ws.pe_caps.as<int32_t>(), ws.pe_reg_off2.as<int64_t>(), T, ws.scan_tmp.as<int64_t>()));
         int64_t tot = 0;
         PE_OK(hipMemcpyAsync(&tot, ws.pe_reg_off2.as<int64_t>() + T, 8, hipMemcpyDeviceToHost, ws.stream));
         PE_OK(hipStreamSynchronize(ws.stream));
@@ -862,7 +1112,7 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
         }
         TIMED(ws, K_FINAL, launch_pe_out(ws.stream, ix->d, opt, tv, regs2, reg_off2, tv.n_regs, ws.pe_ints2.as<int32_t>(), pes, ws.pe_states.p,
                                          ws.job_out.p, ws.job_cig.as<uint32_t>(), ws.job_cig_cap));
-        TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.out_len, tv.out_off, T));
+        TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.out_len, tv.out_off, T, ws.scan_tmp.as<int64_t>()));
         int64_t out_total = 0;
         PE_OK(hipMemcpyAsync(&out_total, tv.out_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
         PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
@@ -870,12 +1120,7 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
         if (err & ERR_OUT_CAP) { ws.out_cap_hint *= 4; continue; }
         if (err & ERR_ZPOOL) { pe_zpool = std::max(pe_zpool * 4, ws.zpool_cap * 4); continue; }
         if (err) { fprintf(stderr, "[bwamem_hip] device error flags %d in the paired-end phase 2\n", err); return false; }
-        to.bytes = (size_t)out_total; to.d = nullptr;
-        if (out_total > 0) {
-            PE_OK(hipMalloc((void**)&to.d, (size_t)out_total));
-            TIMED(ws, K_PACK, launch_pack(ws.stream, tv, to.d));
-            PE_OK(hipStreamSynchronize(ws.stream));
-        }
+        PE_REQ(emit_tile(ws, b, tile_index, tv, out_total, to));
         timed_collect(ws);
         return true;
     }
@@ -884,7 +1129,7 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
 #undef PE_REQ
 
 // what phase 1 of a paired-end call leaves behind for phase 2
-struct PeCall { std::vector<TileSpec> specs; std::vector<PeTile> tiles; int64_t read_id0 = 0; };
+struct PeCall { std::deque<PeTile> tiles; int64_t read_id0 = 0; };
 static void pe_call_free(bwamem_batch_s* b)
 {
     if (!b->pe) return;
@@ -901,17 +1146,16 @@ static bool pe_begin(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes0, bwa
     if (pes0 && !build_pair_tab(ix, pes0)) return false;
     PeCall* pc = b->pe = new PeCall();
     pc->read_id0 = read_id0;
-    pc->specs = plan_tiles(b, opt, true, false);
-    const std::vector<TileSpec>& specs = pc->specs;
-    for (const TileSpec& t : specs) if (!read_length_ok(ix, t.L)) { pe_call_free(b); return false; }
-    pc->tiles.resize(specs.size());
-    std::vector<PeTile>& tiles = pc->tiles;
-    b->tiles.assign(specs.size(), TileOut());
-    if (!run_tiles_seeded(ix, opt, b, specs, [&](Workspace& w, size_t i, const SeedStore& store, uint32_t chunk_r0) {
-            if (!pe_phase1_tile(ix, w, opt, b, read_id0, specs[i], &tiles[i], store, chunk_r0, pes0 == nullptr)) return false;
+    CallPipe pp;
+    pp.on_new_tiles = [&](size_t n) { pc->tiles.resize(pc->tiles.size() + n); b->tiles.resize(b->tiles.size() + n); b->sink.add_tiles(n); };
+    if (!run_pipeline(ix, opt, b, true, pp, [&](Workspace& w, size_t i, const TileSpec& spec, const SeedStore& store, uint32_t chunk_r0) {
+            if (!read_length_ok(ix, spec.L)) return false;
+            PeTile* pt; TileOut* to;
+            { std::lock_guard<std::mutex> lk(pp.mu); pt = &pc->tiles[i]; to = &b->tiles[i]; }     // (the deques grow while tiles run; their elements stay put)
+            if (!pe_phase1_tile(ix, w, opt, b, read_id0, spec, pt, store, chunk_r0, pes0 == nullptr)) return false;
             if (!pes0) return true;
-            const bool ok = pe_phase2_tile(ix, w, opt, b, read_id0, &tiles[i], pes0, b->tiles[i]);
-            tiles[i].n_regs.release(); tiles[i].regs.release(); tiles[i].reg_off.release();
+            const bool ok = pe_phase2_tile(ix, w, opt, b, read_id0, i, pt, pes0, *to);
+            pt->n_regs.release(); pt->regs.release(); pt->reg_off.release();
             return ok;
         })) { pe_call_free(b); return false; }
     if (pes0) {
@@ -926,29 +1170,30 @@ static bool pe_finish(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, bwa
 {
     if (!b->pe) return false;
     if (!build_pair_tab(ix, pes)) { pe_call_free(b); return false; }
-    const std::vector<TileSpec>& specs = b->pe->specs;
-    std::vector<PeTile>& tiles = b->pe->tiles;
+    std::deque<PeTile>& tiles = b->pe->tiles;
     const int64_t read_id0 = b->pe->read_id0;
     const char* env_s = getenv("BWAMEM_HIP_STREAMS");
-    const int n_workers = std::max(1, std::min<int>((int)specs.size(), env_s ? atoi(env_s) : 4));
+    const int n_workers = std::max(1, std::min<int>((int)tiles.size(), env_s ? atoi(env_s) : 4));
     while ((int)ix->extra_ws.size() < n_workers - 1) ix->extra_ws.push_back(new Workspace());
     std::atomic<size_t> next(0);
     std::atomic<bool> failed(false);
     auto worker = [&](int k) {
-        Workspace& w = k == 0 ? ix->ws : *ix->extra_ws[k - 1];
-        if (hipSetDevice(ix->device) != hipSuccess) { failed = true; return; }
-        if (!w.stream && hipStreamCreate(&w.stream) != hipSuccess) { failed = true; return; }
-        while (!failed) {
-            const size_t i = next++;
-            if (i >= specs.size()) break;
-            if (!pe_phase2_tile(ix, w, opt, b, read_id0, &tiles[i], pes, b->tiles[i])) failed = true;
-        }
+        try {
+            Workspace& w = k == 0 ? ix->ws : *ix->extra_ws[k - 1];
+            w.dev_lds = ix->d.lds_bytes;
+            if (hipSetDevice(ix->device) != hipSuccess || (!w.stream && hipStreamCreate(&w.stream) != hipSuccess)) { failed = true; b->sink.abort(); return; }
+            while (!failed) {
+                const size_t i = next++;
+                if (i >= tiles.size()) break;
+                if (!pe_phase2_tile(ix, w, opt, b, read_id0, i, &tiles[i], pes, b->tiles[i])) { failed = true; b->sink.abort(); }
+            }
+        } catch (const std::exception& ex) { fprintf(stderr, "[bwamem_hip] %s\n", ex.what()); failed = true; b->sink.abort(); }
     };
     std::vector<std::thread> th;
     for (int k = 1; k < n_workers; ++k) th.emplace_back(worker, k);
     worker(0);
     for (std::thread& t : th) t.join();
-    if (!failed) for (const TileOut& t : b->tiles) b->result_bytes += t.bytes;
+    if (!failed) { for (const TileOut& t : b->tiles) b->result_bytes += t.bytes; b->sink.last_total = b->result_bytes; }
     pe_call_free(b);
     return !failed;
 }
@@ -978,32 +1223,59 @@ static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes
 // therefore kept in flight on separate HIP streams (one host thread + workspace each) so that one tile's tail
 // overlaps the next tile's bulk.
 // pe_step = 1: only phase 1 of a paired-end call (bwamem_hip_batch_pe_begin)
+static void release_tile_outputs(bwamem_batch_s* b)
+{
+    for (TileOut& t : b->tiles) if (t.d && t.owned) (void)hipFree(t.d);
+    b->tiles.clear(); b->result_bytes = 0;
+}
+
 static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, bwamem_batch_s* b, int64_t read_id0, int pe_step = 0)
 {
     HIP_OK(hipSetDevice(ix->device));
     Workspace& ws = ix->ws;
     if (!ws.stream) HIP_OK(hipStreamCreate(&ws.stream));
-    for (TileOut& t : b->tiles) if (t.d) (void)hipFree(t.d);
-    b->tiles.clear(); b->result_bytes = 0;
+    release_tile_outputs(b);
     pe_call_free(b);
+    b->sink.begin_call(b->n_reads);
     if (b->n_reads == 0) return true;
-    HIP_OK(hipMemcpyAsync(b->d_seq.p, b->d_raw.p, b->n_bytes, hipMemcpyDeviceToDevice, ws.stream));
-    TIMED(ws, K_ENCODE, launch_encode(ws.stream, b->d_seq.as<uint8_t>(), (int64_t)b->n_bytes));
-    HIP_OK(hipStreamSynchronize(ws.stream));
-    timed_collect(ws);
-    if (pe_step == 1) return pe_begin(ix, opt, nullptr, b, read_id0);
-    if (opt.flag & MEM_F_PE) return align_batch_pe(ix, opt, pes, b, read_id0);
-    const std::vector<TileSpec> specs = plan_tiles(b, opt, false, false);
-    for (const TileSpec& t : specs) if (!read_length_ok(ix, t.L)) return false;
-    b->tiles.assign(specs.size(), TileOut());
-    if (!run_tiles_seeded(ix, opt, b, specs, [&](Workspace& w, size_t i, const SeedStore& store, uint32_t chunk_r0) {
-            return run_tile_se(ix, w, opt, b, read_id0, specs[i], b->tiles[i], store, chunk_r0, w.out_cap_hint);
-        })) return false;
-    for (const TileOut& t : b->tiles) b->result_bytes += t.bytes;
-    return true;
+    if (!b->h_payload) {                                   // resident batch: fresh working copy of the bases
+        HIP_OK(hipMemcpyAsync(b->d_seq.p, b->d_raw.p, b->n_bytes, hipMemcpyDeviceToDevice, ws.stream));
+        TIMED(ws, K_ENCODE, launch_encode(ws.stream, b->d_seq.as<uint8_t>(), (int64_t)b->n_bytes));
+        HIP_OK(hipStreamSynchronize(ws.stream));
+        timed_collect(ws);
+        // the response of the previous call on this batch sizes the device slab of this one (no allocation per tile)
+        if (!b->sink.to_host && b->sink.last_total && !b->sink.pool.ensure(b->sink.last_total + b->sink.last_total / 16 + 4096)) return false;
+    } else b->n_bytes = 0;
+    bool ok;
+    if (pe_step == 1) ok = pe_begin(ix, opt, nullptr, b, read_id0);
+    else if (opt.flag & MEM_F_PE) ok = align_batch_pe(ix, opt, pes, b, read_id0);
+    else {
+        CallPipe pp;
+        pp.on_new_tiles = [&](size_t n) { b->tiles.resize(b->tiles.size() + n); b->sink.add_tiles(n); };
+        ok = run_pipeline(ix, opt, b, false, pp, [&](Workspace& w, size_t i, const TileSpec& spec, const SeedStore& store, uint32_t chunk_r0) {
+            if (!read_length_ok(ix, spec.L)) return false;
+            TileOut* to;
+            { std::lock_guard<std::mutex> lk(pp.mu); to = &b->tiles[i]; }
+            return run_tile_se(ix, w, opt, b, read_id0, i, spec, *to, store, chunk_r0, w.out_cap_hint);
+        });
+        if (ok) for (const TileOut& t : b->tiles) b->result_bytes += t.bytes;
+    }
+    if (ok && pe_step != 1) b->sink.last_total = b->result_bytes;
+    return ok;
 }
 
 // ------------------------------------------------------------------------------------------ C ABI
+// No C++ exception may unwind through a JNI / ctypes frame (it would take the JVM down): the exported functions report
+// failure the way the reference's do (NULL / non-zero), whatever went wrong inside (std::bad_alloc from a request-sized
+// vector, std::length_error from an absurd nSeqs, ...).
+template <typename R, typename F> static R guarded(const char* what, R fail, F&& f) noexcept
+{
+    try { return f(); }
+    catch (const std::exception& ex) { fprintf(stderr, "[bwamem_hip] %s: %s\n", what, ex.what()); }
+    catch (...) { fprintf(stderr, "[bwamem_hip] %s: unknown exception\n", what); }
+    return fail;
+}
+
 extern "C" {
 
 int bwamem_hip_set_device(int device) { g_device = device; return hipSetDevice(device) == hipSuccess ? 0 : -1; }
@@ -1035,47 +1307,53 @@ mem_opt_t* jnibwa_createDefaultOptions(void)
 
 int jnibwa_createReferenceIndex(const char* refFileName, const char* indexPrefix, const char* algoName)
 {
-    if (algoName && strcmp(algoName, "auto") && strcmp(algoName, "is") && strcmp(algoName, "rb2")) return -1;
-    std::string err;
-    if (!build_index_files(refFileName, indexPrefix, &err)) { fprintf(stderr, "[bwamem_hip] index build failed: %s\n", err.c_str()); return 1; }
-    return 0;
+    return guarded("jnibwa_createReferenceIndex", 1, [&]() -> int {
+        if (algoName && strcmp(algoName, "auto") && strcmp(algoName, "is") && strcmp(algoName, "rb2")) return -1;
+        std::string err;
+        if (!build_index_files(refFileName, indexPrefix, &err)) { fprintf(stderr, "[bwamem_hip] index build failed: %s\n", err.c_str()); return 1; }
+        return 0;
+    });
 }
 
 int jnibwa_createIndexFile(const char* refName, const char* imgName)
 {
-    std::string err;
-    std::vector<uint8_t> img = image_from_index_files(refName, &err);
-    if (img.empty()) { printf("Failed to load index %s: %s\n", refName, err.c_str()); return 2; }
-    int fd = open(imgName, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-    if (fd == -1) { printf("Failed to open %s for writing: %s\n", imgName, strerror(errno)); return 2; }
-    size_t len = img.size();
-    const uint8_t* buf = img.data();
-    while (len) {
-        size_t to_write = std::min<size_t>(len, (size_t)1 << 30);
-        if (write(fd, buf, to_write) != (ssize_t)to_write) { printf("Failed to write %s: %s\n", imgName, strerror(errno)); close(fd); return 2; }
-        buf += to_write; len -= to_write;
-    }
-    if (close(fd) != 0) { printf("Failed to close %s: %s\n", imgName, strerror(errno)); return 2; }
-    return 0;
+    return guarded("jnibwa_createIndexFile", 2, [&]() -> int {
+        std::string err;
+        std::vector<uint8_t> img = image_from_index_files(refName, &err);
+        if (img.empty()) { printf("Failed to load index %s: %s\n", refName, err.c_str()); return 2; }
+        int fd = open(imgName, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd == -1) { printf("Failed to open %s for writing: %s\n", imgName, strerror(errno)); return 2; }
+        size_t len = img.size();
+        const uint8_t* buf = img.data();
+        while (len) {
+            size_t to_write = std::min<size_t>(len, (size_t)1 << 30);
+            if (write(fd, buf, to_write) != (ssize_t)to_write) { printf("Failed to write %s: %s\n", imgName, strerror(errno)); close(fd); return 2; }
+            buf += to_write; len -= to_write;
+        }
+        if (close(fd) != 0) { printf("Failed to close %s: %s\n", imgName, strerror(errno)); return 2; }
+        return 0;
+    });
 }
 
 bwaidx_t* jnibwa_openIndex(int fd)
 {
-    struct stat st;
-    if (fstat(fd, &st) == -1) { close(fd); return 0; }
-    void* mem = mmap(0, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
-    close(fd);
-    if (mem == MAP_FAILED) return 0;
-    bwaidx_s* ix = new bwaidx_s();
-    ix->mem = (uint8_t*)mem; ix->l_mem = (size_t)st.st_size; ix->mmapped = true; ix->device = g_device;
-    if (!parse_index_image(ix->mem, ix->l_mem, ix->h) || ix->h.seq_len >= (1ull << 37) || !upload_index(ix)) {   // 37-bit ranks: packed SMEM candidates
-        fprintf(stderr, "[bwamem_hip] cannot open index image (malformed image or no usable HIP device)\n");
-        free_index(ix);
-        munmap(mem, (size_t)st.st_size);
-        delete ix;
-        return 0;
-    }
-    return ix;
+    return guarded("jnibwa_openIndex", (bwaidx_t*)0, [&]() -> bwaidx_t* {
+        struct stat st;
+        if (fstat(fd, &st) == -1) { close(fd); return 0; }
+        void* mem = mmap(0, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+        close(fd);
+        if (mem == MAP_FAILED) return 0;
+        bwaidx_s* ix = new bwaidx_s();
+        ix->mem = (uint8_t*)mem; ix->l_mem = (size_t)st.st_size; ix->mmapped = true; ix->device = g_device;
+        if (!parse_index_image(ix->mem, ix->l_mem, ix->h) || ix->h.seq_len >= (1ull << 37) || !upload_index(ix)) {   // 37-bit ranks: packed SMEM candidates
+            fprintf(stderr, "[bwamem_hip] cannot open index image (malformed image or no usable HIP device)\n");
+            free_index(ix);
+            munmap(mem, (size_t)st.st_size);
+            delete ix;
+            return 0;
+        }
+        return ix;
+    });
 }
 
 int jnibwa_destroyIndex(bwaidx_t* pIdx)
@@ -1089,18 +1367,37 @@ int jnibwa_destroyIndex(bwaidx_t* pIdx)
 
 void* jnibwa_getRefContigNames(bwaidx_t* pIdx, size_t* pBufSize)
 {
-    const std::vector<ContigInfo>& c = pIdx->h.contigs;
-    size_t bufSize = 4 + 4 * c.size();
-    for (const ContigInfo& ci : c) bufSize += ci.name.size() + 1;   // the reference over-allocates by one byte per name (jnibwa.c:181)
-    char* bufMem = (char*)calloc(bufSize, 1);
-    *(int32_t*)bufMem = (int32_t)c.size();
-    char* p = bufMem + 4;
-    for (const ContigInfo& ci : c) {
-        *(int32_t*)p = (int32_t)ci.name.size(); p += 4;
-        memcpy(p, ci.name.data(), ci.name.size()); p += ci.name.size();
-    }
-    *pBufSize = bufSize;
-    return bufMem;
+    return guarded("jnibwa_getRefContigNames", (void*)0, [&]() -> void* {
+        const std::vector<ContigInfo>& c = pIdx->h.contigs;
+        size_t bufSize = 4 + 4 * c.size();
+        for (const ContigInfo& ci : c) bufSize += ci.name.size() + 1;   // the reference over-allocates by one byte per name (jnibwa.c:181)
+        char* bufMem = (char*)calloc(bufSize, 1);
+        *(int32_t*)bufMem = (int32_t)c.size();
+        char* p = bufMem + 4;
+        for (const ContigInfo& ci : c) {
+            *(int32_t*)p = (int32_t)ci.name.size(); p += 4;
+            memcpy(p, ci.name.data(), ci.name.size()); p += ci.name.size();
+        }
+        *pBufSize = bufSize;
+        return bufMem;
+    });
+}
+
+int bwamem_hip_index_contig_lengths(bwaidx_t* idx, int64_t* lens, int cap)
+{
+    if (!idx) return -1;
+    const int n = (int)idx->h.contigs.size();
+    if (lens) for (int i = 0; i < n && i < cap; ++i) lens[i] = idx->h.contigs[i].len;
+    return n;
+}
+
+int bwamem_hip_index_unpack_pac(bwaidx_t* idx, int64_t start, int64_t n, void* d_dst)
+{
+    if (!idx || !d_dst || start < 0 || n < 0 || start + n > idx->d.l_pac) return -1;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (hipSetDevice(idx->device) != hipSuccess) return -1;
+    launch_unpack_pac(0, idx->d, start, n, (uint8_t*)d_dst);
+    return hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess ? 0 : -1;
 }
 
 // the request's strings (payload = pSeq + 4) with their offsets already known: device copies of both
@@ -1120,97 +1417,114 @@ static bwamem_batch_s* batch_from_offsets(bwaidx_t* idx, const char* payload, ui
 
 bwamem_batch_t* bwamem_hip_batch_upload(bwaidx_t* idx, const char* pSeq, size_t nBytes)
 {
-    if (!idx || !pSeq || nBytes < 4) return 0;
-    uint32_t n_reads; memcpy(&n_reads, pSeq, 4);
-    const char* p = pSeq + 4; const char* end = pSeq + nBytes;
-    std::vector<int64_t> off((size_t)n_reads + 1);
-    for (uint32_t i = 0; i < n_reads; ++i) {              // jnibwa.c:204-212 (strlen walk)
-        off[i] = p - (pSeq + 4);
-        const char* z = (const char*)memchr(p, 0, (size_t)(end - p));
-        if (!z) { fprintf(stderr, "[bwamem_hip] request buffer ends inside read %u\n", i); return 0; }
-        p = z + 1;
-    }
-    off[n_reads] = p - (pSeq + 4);
-    return batch_from_offsets(idx, pSeq + 4, n_reads, std::move(off));
+    return guarded("bwamem_hip_batch_upload", (bwamem_batch_t*)0, [&]() -> bwamem_batch_t* {
+        if (!idx || !pSeq || nBytes < 4) return 0;
+        uint32_t n_reads; memcpy(&n_reads, pSeq, 4);
+        const char* p = pSeq + 4; const char* end = pSeq + nBytes;
+        std::vector<int64_t> off((size_t)n_reads + 1);
+        for (uint32_t i = 0; i < n_reads; ++i) {              // jnibwa.c:204-212 (strlen walk)
+            off[i] = p - (pSeq + 4);
+            const char* z = (const char*)memchr(p, 0, (size_t)(end - p));
+            if (!z) { fprintf(stderr, "[bwamem_hip] request buffer ends inside read %u\n", i); return 0; }
+            p = z + 1;
+        }
+        off[n_reads] = p - (pSeq + 4);
+        return batch_from_offsets(idx, pSeq + 4, n_reads, std::move(off));
+    });
 }
 
 bwamem_batch_t* bwamem_hip_batch_wrap_device(bwaidx_t* idx, const void* d_payload, size_t nBytes, uint32_t nReads, const int64_t* h_offsets)
 {
-    if (!idx || !d_payload || !h_offsets) return 0;
-    if (hipSetDevice(idx->device) != hipSuccess) return 0;
-    bwamem_batch_s* b = new bwamem_batch_s();
-    b->idx = idx; b->n_reads = nReads; b->n_bytes = nBytes;
-    b->h_off.assign(h_offsets, h_offsets + (size_t)nReads + 1);
-    bool ok = b->h_off[nReads] == (int64_t)nBytes
-        && b->d_raw.ensure(nBytes + 64) && b->d_seq.ensure(nBytes + 64) && b->d_off.ensure(((size_t)nReads + 1) * 8)
-        && hipMemcpy(b->d_raw.p, d_payload, nBytes, hipMemcpyDeviceToDevice) == hipSuccess
-        && hipMemcpy(b->d_off.p, b->h_off.data(), ((size_t)nReads + 1) * 8, hipMemcpyHostToDevice) == hipSuccess;
-    if (!ok) { fprintf(stderr, "[bwamem_hip] batch_wrap_device failed\n"); bwamem_hip_batch_free(b); return 0; }
-    return b;
+    return guarded("bwamem_hip_batch_wrap_device", (bwamem_batch_t*)0, [&]() -> bwamem_batch_t* {
+        if (!idx || !d_payload || !h_offsets) return 0;
+        if (hipSetDevice(idx->device) != hipSuccess) return 0;
+        bwamem_batch_s* b = new bwamem_batch_s();
+        b->idx = idx; b->n_reads = nReads; b->n_bytes = nBytes;
+        b->h_off.assign(h_offsets, h_offsets + (size_t)nReads + 1);
+        bool ok = b->h_off[nReads] == (int64_t)nBytes
+            && b->d_raw.ensure(nBytes + 64) && b->d_seq.ensure(nBytes + 64) && b->d_off.ensure(((size_t)nReads + 1) * 8)
+            && hipMemcpy(b->d_raw.p, d_payload, nBytes, hipMemcpyDeviceToDevice) == hipSuccess
+            && hipMemcpy(b->d_off.p, b->h_off.data(), ((size_t)nReads + 1) * 8, hipMemcpyHostToDevice) == hipSuccess;
+        if (!ok) { fprintf(stderr, "[bwamem_hip] batch_wrap_device failed\n"); bwamem_hip_batch_free(b); return 0; }
+        return b;
+    });
 }
 
 int bwamem_hip_batch_align(bwaidx_t* idx, const mem_opt_t* opt, const mem_pestat_t* pes, bwamem_batch_t* b, int64_t read_id0)
 {
-    if (!idx || !opt || !b) return -1;
-    std::lock_guard<std::mutex> lk(idx->mu);
-    MemOpt o; memcpy(&o, opt, sizeof o);
-    return align_batch(idx, o, (const MemPestat*)pes, b, read_id0) ? 0 : -1;
+    return guarded("bwamem_hip_batch_align", -1, [&]() -> int {
+        if (!idx || !opt || !b) return -1;
+        std::lock_guard<std::mutex> lk(idx->mu);
+        MemOpt o; memcpy(&o, opt, sizeof o);
+        return align_batch(idx, o, (const MemPestat*)pes, b, read_id0) ? 0 : -1;
+    });
 }
 
 int bwamem_hip_batch_pe_begin(bwaidx_t* idx, const mem_opt_t* opt, bwamem_batch_t* b, int64_t read_id0)
 {
-    if (!idx || !opt || !b) return -1;
-    std::lock_guard<std::mutex> lk(idx->mu);
-    MemOpt o; memcpy(&o, opt, sizeof o);
-    if (!(o.flag & MEM_F_PE)) return -1;
-    return align_batch(idx, o, nullptr, b, read_id0, 1) ? 0 : -1;
+    return guarded("bwamem_hip_batch_pe_begin", -1, [&]() -> int {
+        if (!idx || !opt || !b) return -1;
+        std::lock_guard<std::mutex> lk(idx->mu);
+        MemOpt o; memcpy(&o, opt, sizeof o);
+        if (!(o.flag & MEM_F_PE)) return -1;
+        return align_batch(idx, o, nullptr, b, read_id0, 1) ? 0 : -1;
+    });
 }
 
 size_t bwamem_hip_batch_pe_candidates(const bwamem_batch_t* b, int8_t* dir, int64_t* isize)
 {
-    if (!b) return 0;
-    std::vector<int8_t> d; std::vector<int64_t> is;
-    pe_candidates(b, d, is);
-    if (dir && isize && !d.empty()) { memcpy(dir, d.data(), d.size()); memcpy(isize, is.data(), is.size() * 8); }
-    return d.size();
+    return guarded("bwamem_hip_batch_pe_candidates", (size_t)0, [&]() -> size_t {
+        if (!b) return 0;
+        std::vector<int8_t> d; std::vector<int64_t> is;
+        pe_candidates(b, d, is);
+        if (dir && isize && !d.empty()) { memcpy(dir, d.data(), d.size()); memcpy(isize, is.data(), is.size() * 8); }
+        return d.size();
+    });
 }
 
 void bwamem_hip_pestat(const mem_opt_t* opt, const int8_t* dir, const int64_t* isize, size_t n, mem_pestat_t* pes)
 {
-    MemOpt o; memcpy(&o, opt, sizeof o);
-    std::vector<int8_t> d(dir, dir + n); std::vector<int64_t> is(isize, isize + n);
-    host_pestat(o, d, is, (MemPestat*)pes);
+    (void)guarded("bwamem_hip_pestat", 0, [&]() -> int {
+        MemOpt o; memcpy(&o, opt, sizeof o);
+        std::vector<int8_t> d(dir, dir + n); std::vector<int64_t> is(isize, isize + n);
+        host_pestat(o, d, is, (MemPestat*)pes);
+        return 0;
+    });
 }
 
 int bwamem_hip_batch_pe_finish(bwaidx_t* idx, const mem_opt_t* opt, const mem_pestat_t* pes, bwamem_batch_t* b)
 {
-    if (!idx || !opt || !b || !pes) return -1;
-    std::lock_guard<std::mutex> lk(idx->mu);
-    if (hipSetDevice(idx->device) != hipSuccess) return -1;
-    MemOpt o; memcpy(&o, opt, sizeof o);
-    return pe_finish(idx, o, (const MemPestat*)pes, b) ? 0 : -1;
+    return guarded("bwamem_hip_batch_pe_finish", -1, [&]() -> int {
+        if (!idx || !opt || !b || !pes) return -1;
+        std::lock_guard<std::mutex> lk(idx->mu);
+        if (hipSetDevice(idx->device) != hipSuccess) return -1;
+        MemOpt o; memcpy(&o, opt, sizeof o);
+        return pe_finish(idx, o, (const MemPestat*)pes, b) ? 0 : -1;
+    });
 }
 
 size_t bwamem_hip_batch_result_bytes(const bwamem_batch_t* b) { return b->result_bytes; }
 
 int bwamem_hip_batch_download(bwamem_batch_t* b, void* dst)
 {
-    if (hipSetDevice(b->idx->device) != hipSuccess) return -1;
-    uint8_t* p = (uint8_t*)dst;
-    for (const TileOut& t : b->tiles) {
-        if (t.bytes && hipMemcpy(p, t.d, t.bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        p += t.bytes;
-    }
-    return 0;
+    return guarded("bwamem_hip_batch_download", -1, [&]() -> int {
+        if (hipSetDevice(b->idx->device) != hipSuccess) return -1;
+        uint8_t* p = (uint8_t*)dst;
+        for (const TileOut& t : b->tiles) {
+            if (t.bytes && hipMemcpy(p, t.d, t.bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            p += t.bytes;
+        }
+        return 0;
+    });
 }
 
 void bwamem_hip_batch_free(bwamem_batch_t* b)
 {
     if (!b) return;
     (void)hipSetDevice(b->idx->device);
-    for (TileOut& t : b->tiles) if (t.d) (void)hipFree(t.d);
+    release_tile_outputs(b);
     pe_call_free(b);
-    b->d_raw.release(); b->d_seq.release(); b->d_off.release();
+    b->d_raw.release(); b->d_seq.release(); b->d_off.release(); b->sink.pool.release();
     delete b;
 }
 
@@ -1218,21 +1532,26 @@ void* jnibwa_createAlignments(bwaidx_t* pIdx, mem_opt_t* pOpts, mem_pestat_t* pe
 {
     if (pBufSize) *pBufSize = 0;
     if (!pIdx || !pOpts || !pSeq) return 0;
-    // the request carries no length: walk the NUL-terminated strings exactly as the reference does (jnibwa.c:204-212),
-    // once, keeping the offsets
-    uint32_t n; memcpy(&n, pSeq, 4);
-    std::vector<int64_t> off((size_t)n + 1);
-    { const char* p = pSeq + 4; for (uint32_t i = 0; i < n; ++i) { off[i] = p - (pSeq + 4); p += strlen(p) + 1; } off[n] = p - (pSeq + 4); }
-    bwamem_batch_t* b = batch_from_offsets(pIdx, pSeq + 4, n, std::move(off));
-    if (!b) return 0;
+    // The request carries no length; the reference walks its NUL-terminated strings first (jnibwa.c:204-212), aligns, then
+    // copies the records out.  Here the three overlap: a producer thread walks the buffer and streams it to the device
+    // stretch by stretch (read offsets are found there), tiles are aligned as soon as their stretch is resident, and every
+    // finished tile's records go straight into the malloc'ed block that is returned.
     void* res = 0;
-    if (bwamem_hip_batch_align(pIdx, pOpts, peStats, b, 0) == 0) {
-        size_t sz = bwamem_hip_batch_result_bytes(b);
-        res = malloc(sz ? sz : 1);
-        if (res && bwamem_hip_batch_download(b, res) != 0) { free(res); res = 0; }
-        if (res && pBufSize) *pBufSize = sz;
-    }
-    bwamem_hip_batch_free(b);
+    try {
+        uint32_t n; memcpy(&n, pSeq, 4);
+        bwamem_batch_s* b = new bwamem_batch_s();
+        b->idx = pIdx; b->n_reads = n; b->h_payload = pSeq + 4; b->sink.to_host = true;
+        {
+            std::lock_guard<std::mutex> lk(pIdx->mu);
+            MemOpt o; memcpy(&o, pOpts, sizeof o);
+            if (align_batch(pIdx, o, (const MemPestat*)peStats, b, 0)) {
+                res = b->sink.take(b->result_bytes);
+                if (res && pBufSize) *pBufSize = b->result_bytes;
+            }
+        }
+        bwamem_hip_batch_free(b);
+    } catch (const std::exception& ex) { fprintf(stderr, "[bwamem_hip] createAlignments: %s\n", ex.what()); res = 0; }
+      catch (...) { res = 0; }
     return res;
 }
 

@@ -59,6 +59,11 @@ const char* jnibwa_getVersion(void);
 int bwamem_hip_set_device(int device);        /* device used by subsequently opened indexes */
 int bwamem_hip_device_count(void);
 
+/* Tooling (bench.py --image): the contig lengths of an open index (returns the number of contigs; lens may be NULL), and
+ * n bases of its packed reference from position start, one code 0..3 per byte, into DEVICE memory d_dst.  0 = ok. */
+int bwamem_hip_index_contig_lengths(bwaidx_t* idx, int64_t* lens, int cap);
+int bwamem_hip_index_unpack_pac(bwaidx_t* idx, int64_t start, int64_t n, void* d_dst);
+
 typedef struct bwamem_batch_s bwamem_batch_t; /* a request resident in HBM */
 
 /* upload a request buffer (same wire format as pSeq above); the host buffer is left untouched */

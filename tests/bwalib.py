@@ -41,12 +41,23 @@ def build_emu():
 
 
 class Lib:
-    """One library exposing the jnibwa ABI under a symbol prefix ('jnibwa_' or 'oracle_')."""
+    """One library exposing the jnibwa ABI under a symbol prefix ('jnibwa_' or 'oracle_').  A stock libbwa.Linux.so
+    (reference build) has the jnibwa_* entry points of jnibwa.h:11-16 but neither of this repo's two helpers: its default
+    options come from upstream's mem_opt_init and its buffers are freed with libc free."""
 
     def __init__(self, path, prefix):
         self.path, self.prefix = path, prefix
         self.dll = ctypes.CDLL(path)
-        f = lambda name: getattr(self.dll, prefix + name)
+        libc = ctypes.CDLL(None)
+
+        def f(name):
+            if hasattr(self.dll, prefix + name):
+                return getattr(self.dll, prefix + name)
+            if name == "createDefaultOptions":
+                return self.dll.mem_opt_init
+            if name == "free":
+                return libc.free
+            raise AttributeError(prefix + name)
         self._createIndexFile = f("createIndexFile"); self._createIndexFile.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
         self._openIndex = f("openIndex"); self._openIndex.restype = ctypes.c_void_p; self._openIndex.argtypes = [ctypes.c_int]
         self._destroyIndex = f("destroyIndex"); self._destroyIndex.argtypes = [ctypes.c_void_p]
@@ -106,6 +117,41 @@ def product_lib(emu=False):
 
 def oracle_lib():
     return Lib(ORACLE_LIB, "oracle_")
+
+
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+
+
+def stock_libbwa():
+    """The hooks that turn "parity unpinned" into "pinned" the moment the material exists:
+      LIBBWA_PATH     a stock libbwa.Linux.so as the reference's own Makefile builds it (src/main/c/Makefile:22-23), or
+      BWA_ORACLE_SRC  a checkout of lh3/bwa at cb950614, compiled here together with the reference's jnibwa.c where it lies
+                      under /root/reference (recipe: oracle/Makefile target `ref`, output oracle/_ref/libbwa_ref.so)
+    -> a Lib behind the same jnibwa_* ABI, used as a second checker by every parity test and as bench.py's CPU baseline
+    (cpu_baseline.kind = "reference"); None when neither is set (this offline image has no bwa source)."""
+    path = os.environ.get("LIBBWA_PATH")
+    if not path and os.environ.get("BWA_ORACLE_SRC"):
+        make(os.path.join(ROOT, "oracle"), "ref", "BWA_ORACLE_SRC=" + os.environ["BWA_ORACLE_SRC"])
+        path = os.path.join(REF_DIR, "libbwa_ref.so")
+    if not path:
+        return None
+    if not os.path.exists(path):
+        raise FileNotFoundError("LIBBWA_PATH / BWA_ORACLE_SRC is set but %s does not exist" % path)
+    return Lib(path, "jnibwa_")
+
+
+def check_against_stock(img, opts, request, got, pes=None):
+    """second checker: when a stock libbwa is available, `got` must also equal its response (no-op otherwise)"""
+    ref = stock_libbwa()
+    if ref is None:
+        return False
+    h = ref.open_index(img)
+    try:
+        want = ref.align_raw(h, opts, request, pes)
+    finally:
+        ref.destroy_index(h)
+    assert got == want, "response differs from the stock libbwa at %s" % ref.path
+    return True
 
 
 def set_opt(opts, **kw):

@@ -128,10 +128,13 @@ static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); 
 static inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) { *free_b = *total_b = (size_t)1 << 36; return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (void*)1; return hipSuccess; }
-enum { hipStreamNonBlocking = 1 };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
 static inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (void*)1; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)1; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return posix_memalign(p, 256, n ? n : 256) == 0 ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (void*)1; return hipSuccess; }

@@ -23,6 +23,7 @@ def _cmp(emu, oracle, img, reads, **optkw):
     emu.destroy_index(h); oracle.destroy_index(ho)
     assert got is not None
     assert got == want
+    B.check_against_stock(img, opts, req, want)         # LIBBWA_PATH / BWA_ORACLE_SRC: the oracle itself against a stock libbwa
 
 
 def test_emu_golden_reads(emu, oracle, rota_img):
@@ -133,3 +134,40 @@ def test_emu_alt_contigs(emu, oracle, alt_genome):
     for pes in (None, B.pack_pestat(150, 450, 300.0, 30.0)):
         assert emu.align_raw(h, opts, B.pack_request(pairs), pes) == oracle.align_raw(ho, opts, B.pack_request(pairs), pes)
     emu.destroy_index(h); oracle.destroy_index(ho)
+
+
+def test_emu_streamed_request_stretches(emu, oracle, small_genome, monkeypatch):
+    """jnibwa_createAlignments streams the request to the device in stretches cut by read count and by bytes (whole reads,
+    whole pairs); the read offsets come from the device NUL scan.  Tiny stretches must give the same bytes."""
+    seqs, img = small_genome
+    reads = B.simulate_reads(seqs, 40, length=100, seed=33, sub=0.02, indel=0.003) + [b"", b"A", b"", b"ACGT" * 30, b""]
+    monkeypatch.setenv("BWAMEM_HIP_UPLOAD_BYTES", "700")
+    _cmp(emu, oracle, img, reads)
+    pairs = B.simulate_pairs(seqs, 9, length=100, seed=34, ins_mean=300, ins_sd=30)
+    monkeypatch.setenv("BWAMEM_HIP_UPLOAD_BYTES", "301")           # three reads' worth: stretches must still end on a pair
+    h, ho = emu.open_index(img), oracle.open_index(img)
+    opts = B.set_opt(emu.default_options(), flag=B.MEM_F_PE)
+    for rd in (pairs, pairs[:-1]):
+        assert emu.align_raw(h, opts, B.pack_request(rd)) == oracle.align_raw(ho, opts, B.pack_request(rd))
+    emu.destroy_index(h); oracle.destroy_index(ho)
+
+
+def test_stock_libbwa_hook(emu, oracle, rota_img, monkeypatch):
+    """LIBBWA_PATH makes a library with the reference's jnibwa_* ABI a second checker (tests/bwalib.py: stock_libbwa).
+    No stock libbwa exists in this offline image, so the hook is exercised by pointing it at a library that has the ABI --
+    the emulation build -- and must be a clean no-op when unset."""
+    reads = [b"GGCTTTTAATGCTTTTCAGTGGTTGCTGCTCAAGATGGAGTCTACTCAGCAGATGGTAAGCTCTATTATT", b"ACGT" * 20]
+    req = B.pack_request(reads)
+    ho = oracle.open_index(rota_img)
+    want = oracle.align_raw(ho, oracle.default_options(), req)
+    oracle.destroy_index(ho)
+    monkeypatch.delenv("LIBBWA_PATH", raising=False)
+    monkeypatch.delenv("BWA_ORACLE_SRC", raising=False)
+    assert B.stock_libbwa() is None and B.check_against_stock(rota_img, oracle.default_options(), req, want) is False
+    monkeypatch.setenv("LIBBWA_PATH", B.EMU_LIB)
+    assert B.check_against_stock(rota_img, oracle.default_options(), req, want) is True
+    with pytest.raises(AssertionError):
+        B.check_against_stock(rota_img, oracle.default_options(), req, want + b"x")
+    monkeypatch.setenv("LIBBWA_PATH", "/nonexistent/libbwa.Linux.so")
+    with pytest.raises(FileNotFoundError):
+        B.stock_libbwa()

@@ -89,6 +89,7 @@ def _parity(hip, orc, img, reads, **optkw):
             msg = "%d/%d reads differ; first: read %d %r\n  hip    %r\n  oracle %r" % (
                 len(bad), len(reads), bad[0], reads[bad[0]], B.decode_response(sa[bad[0]], 1), B.decode_response(sb[bad[0]], 1))
             pytest.fail(msg)
+        B.check_against_stock(img, opts, req, got)          # LIBBWA_PATH / BWA_ORACLE_SRC: a stock libbwa as second checker
         return got
     finally:
         hip.destroy_index(h); orc.destroy_index(ho)
@@ -195,6 +196,7 @@ def _parity_pe(hip, orc, img, reads, pes=None, **optkw):
             bad = [i for i in range(len(reads)) if sa[i] != sb[i]]
             pytest.fail("%d/%d PE reads differ; first: read %d\n  hip    %r\n  oracle %r" % (
                 len(bad), len(reads), bad[0], B.decode_response(sa[bad[0]], 1), B.decode_response(sb[bad[0]], 1)))
+        B.check_against_stock(img, opts, req, got, pes)
         return got
     finally:
         hip.destroy_index(h); orc.destroy_index(ho)
@@ -387,3 +389,61 @@ def test_parity_alt_contigs_paired_end(hip_lib, oracle, alt_genome):
     _parity_pe(hip_lib, oracle, img, pairs, pes=B.pack_pestat(150, 450, 300.0, 30.0))
     _parity_pe(hip_lib, oracle, img, pairs[:800], flag=B.MEM_F_NO_RESCUE)
     _parity_pe(hip_lib, oracle, img, pairs[:800], flag=B.MEM_F_ALL, max_XA_hits=1)
+
+
+# ---------------------------------------------------------------- sharded calls and the bench launcher
+def test_single_end_call_in_two_shards_with_read_id0(hip_lib, oracle, small_genome):
+    """BASELINE.json config 4 in miniature: one logical single-end call aligned as two shards on the HIP library, each
+    carrying the index of its first read (read_id0 = 0 / n/2).  Reads with tied alignment scores make the tie-break hash of
+    mem_mark_primary_se (hash_64(id + i)) decide which copy is primary, so a shard that ignored read_id0 would differ."""
+    import sharding
+    seqs, img = small_genome
+    g = seqs[0][1]
+    reads = B.simulate_reads(seqs, 3000, length=120, seed=78, sub=0.01)
+    reads += [g[5000:5120], g[9000:9100] + g[9000:9020]] * 600                 # exact repeats of the same read at many read indexes
+    dup = bytearray(B.simulate_reads(seqs, 1, length=120, seed=79, sub=0.0, indel=0.0, n_rate=0.0, random_frac=0.0)[0])
+    reads += [bytes(dup)] * 400
+    ho = oracle.open_index(img)
+    opts = oracle.default_options()
+    want = oracle.align_raw(ho, opts, B.pack_request(reads))
+    # the case can tell: the second half aligned as a call of its own (read_id0 = 0) gives other bytes for some read
+    import ctypes
+    fn = oracle.dll.oracle_createAlignmentsAt
+    fn.restype = ctypes.c_void_p
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_int64]
+    half = len(reads) // 2
+    def oracle_at(lo, hi, id0):
+        req = B.pack_request(reads[lo:hi])
+        rb = ctypes.create_string_buffer(req, len(req)); sz = ctypes.c_size_t()
+        ob = ctypes.create_string_buffer(bytes(opts), 168)
+        return ctypes.string_at(fn(ho, ob, None, rb, ctypes.byref(sz), id0), sz.value)
+    assert oracle_at(0, half, 0) + oracle_at(half, len(reads), half) == want
+    tells = oracle_at(0, half, 0) + oracle_at(half, len(reads), 0) != want
+    oracle.destroy_index(ho)
+    h = hip_lib.open_index(img)
+    try:
+        got = b"".join(sharding.align_shard(hip_lib.dll, h, opts, reads, r, 2) for r in range(2))
+        got3 = b"".join(sharding.align_shard(hip_lib.dll, h, opts, reads, r, 3) for r in range(3))
+    finally:
+        hip_lib.destroy_index(h)
+    assert got == want and got3 == want
+    assert tells, "fixture too weak: no read's records depend on its index within the call"
+
+
+def test_bench_launcher_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no external launcher) must start two ranks itself and print an n_gpus = 2 line.
+    BENCH_REHEARSAL puts both ranks on GPU 0 with gloo: the launcher, the shared image, the barriers and the gather of
+    the per-rank times are what is exercised, not a measurement."""
+    import subprocess
+    env = dict(os.environ, BENCH_REHEARSAL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(B.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--reads", "100000",
+                        "--genome-bp", "8000000", "--contigs", "4", "--cpu-sample", "0", "--h2h-calls", "2"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and len(out["per_rank"]["reads_per_s"]) == 2
+    assert out["value"] > 0 and out["host_to_host"]["reads_per_s"] > 0 and out["host_to_host"]["identical_to_resident_response"] is True
