@@ -13,7 +13,7 @@ namespace emu {
 static const size_t STACK = 512 * 1024;
 
 struct Fiber { ucontext_t ctx; char* stack; bool done; unsigned tid; };
-struct WaveState { int arrive = 0; unsigned gen = 0; int alive = 0; uint64_t alive_mask = 0; uint64_t slots[64]; };
+struct WaveState { int arrive = 0; unsigned gen = 0; int alive = 0; uint64_t alive_mask = 0; uint64_t slots[64]; int row_arrive[4] = {0, 0, 0, 0}; unsigned row_gen[4] = {0, 0, 0, 0}; };
 
 static ucontext_t g_sched;
 static std::vector<Fiber> g_fibers;
@@ -38,6 +38,17 @@ void sync_wave()
     while (w.gen == my) yield();
 }
 
+static int row_alive(const WaveState& w, int row) { return __builtin_popcountll(w.alive_mask >> (16 * row) & 0xffffull); }
+
+void sync_row()
+{
+    WaveState& w = g_waves[g_cur->tid >> 6];
+    const int row = (g_cur->tid & 63) >> 4;
+    unsigned my = w.row_gen[row];
+    if (++w.row_arrive[row] == row_alive(w, row)) { w.row_arrive[row] = 0; ++w.row_gen[row]; return; }
+    while (w.row_gen[row] == my) yield();
+}
+
 void sync_block()
 {
     unsigned my = g_block_gen;
@@ -53,6 +64,7 @@ static void trampoline()
     WaveState& w = g_waves[f->tid >> 6];
     --w.alive; w.alive_mask &= ~(1ull << (f->tid & 63));
     if (w.alive > 0 && w.arrive == w.alive) { w.arrive = 0; ++w.gen; }
+    { const int row = (f->tid & 63) >> 4; const int ra = row_alive(w, row); if (ra > 0 && w.row_arrive[row] == ra) { w.row_arrive[row] = 0; ++w.row_gen[row]; } }
     --g_block_alive;
     if (g_block_alive > 0 && g_block_arrive == g_block_alive) { g_block_arrive = 0; ++g_block_gen; }
     swapcontext(&f->ctx, &g_sched);

@@ -33,6 +33,7 @@ namespace emu {
 void* dyn_smem();
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 void sync_wave();
+void sync_row();      // the 16 lanes of the calling thread's DPP row
 void sync_block();
 uint64_t* wave_slots();      // 64 slots of the calling thread's wave
 uint64_t wave_alive_mask();
@@ -76,17 +77,24 @@ static inline unsigned long long __ballot(int pred)
 }
 static inline void __syncthreads() { emu::sync_block(); }
 
-// DPP subset used by wave_ops.h (gfx9 controls row_shr:n, wave_shr:1, row_bcast:15, row_bcast:31)
+// DPP subset used by wave_ops.h (gfx9 controls quad_perm, row_shl:n, row_shr:n, wave_shl/shr:1, row_mirror, row_half_mirror,
+// row_bcast:15, row_bcast:31).  Controls that stay inside a 16-lane row rendezvous only the lanes of that row, so that the
+// four rows of a wave may run different control flow (as the exec mask lets them on the hardware).
 static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
 {
     uint64_t* s = emu::wave_slots();
     int lane = threadIdx.x & 63, row = lane >> 4, in_row = lane & 15;
+    const bool row_local = ctrl < 0x130 || ctrl == 0x140 || ctrl == 0x141;
     s[lane] = (uint32_t)src;
-    emu::sync_wave();
+    if (row_local) emu::sync_row(); else emu::sync_wave();
     int from = -1;
-    if (ctrl >= 0x111 && ctrl <= 0x11f) { int n = ctrl - 0x110; from = in_row >= n ? lane - n : -1; }
+    if (ctrl >= 0 && ctrl <= 0xff) from = (lane & ~3) | (ctrl >> (2 * (lane & 3)) & 3);
+    else if (ctrl >= 0x101 && ctrl <= 0x10f) { int n = ctrl - 0x100; from = in_row + n <= 15 ? lane + n : -1; }
+    else if (ctrl >= 0x111 && ctrl <= 0x11f) { int n = ctrl - 0x110; from = in_row >= n ? lane - n : -1; }
     else if (ctrl == 0x138) from = lane >= 1 ? lane - 1 : -1;
     else if (ctrl == 0x130) from = lane < 63 ? lane + 1 : -1;
+    else if (ctrl == 0x140) from = (lane & ~15) | (15 - in_row);
+    else if (ctrl == 0x141) from = (lane & ~7) | (7 - (lane & 7));
     else if (ctrl == 0x142) from = row >= 1 ? (row << 4) - 1 : -1;
     else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;
     else { fprintf(stderr, "emu: unsupported DPP control 0x%x\n", ctrl); abort(); }
@@ -96,9 +104,11 @@ static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int b
         if (from >= 0 && (emu::wave_alive_mask() >> from & 1)) r = (int)(uint32_t)s[from];
         else if (bound_ctrl) r = 0;
     }
-    emu::sync_wave();
+    if (row_local) emu::sync_row(); else emu::sync_wave();
     return r;
 }
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_wave_barrier() emu::sync_row()
 #define __builtin_amdgcn_update_dpp emu_update_dpp
 static inline int emu_readlane(int v, int lane) { return __shfl(v, lane); }
 #define __builtin_amdgcn_readlane emu_readlane

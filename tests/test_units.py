@@ -48,12 +48,13 @@ def _check_extend(units, oracle, n_cases, max_q):
     oext.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p] * 5
     rng = np.random.default_rng(11)
     base_opts = oracle.default_options()
+    n_band = [0, 0]
     for it in range(n_cases):
         qlen = int(rng.integers(1, max_q)); tlen = int(rng.integers(1, max_q + 60))
         t = rng.integers(0, 4, size=tlen, dtype=np.uint8)
         # query = mutated copy of the target so that the DP actually extends
         q = np.resize(t, qlen).copy()
-        mut = rng.random(qlen) < rng.choice([0.0, 0.02, 0.1, 0.4])
+        mut = rng.random(qlen) < rng.choice([0.0, 0.01, 0.02, 0.1, 0.4])
         q[mut] = rng.integers(0, 5, size=int(mut.sum()), dtype=np.uint8)
         if rng.random() < 0.4 and qlen > 12:                       # an indel
             cut = int(rng.integers(3, qlen - 3)); k = int(rng.integers(1, 8))
@@ -61,21 +62,45 @@ def _check_extend(units, oracle, n_cases, max_q):
             qlen = len(q)
         kw = dict(a=int(rng.choice([1, 2])), b=int(rng.choice([4, 9, 2])), o_del=int(rng.choice([6, 16, 0])), e_del=int(rng.choice([1, 2])),
                   o_ins=int(rng.choice([6, 16, 0])), e_ins=int(rng.choice([1, 3])))
+        w = int(rng.choice([100, 200, 5, 1])); zdrop = int(rng.choice([100, 0, 10])); end_bonus = int(rng.choice([5, 0])); h0 = int(rng.integers(0, 150))
+        if it % 2 == 0:
+            # the shape production sees most: the extension of a long seed of a well-placed read -- default penalties, the target
+            # longer than the query, a handful of substitutions, now and then an N or a short indel
+            kw = dict(a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1)
+            if rng.random() < 0.3:
+                kw.update(b=int(rng.choice([4, 9])), o_del=int(rng.choice([6, 16])), o_ins=int(rng.choice([6, 16])), e_del=int(rng.choice([1, 2])))
+            qlen = int(rng.integers(2, min(max_q, 200))); tlen = qlen + int(rng.integers(0, 90))
+            t = rng.integers(0, 4, size=tlen, dtype=np.uint8)
+            q = t[:qlen].copy()
+            for pos in rng.integers(0, qlen, size=int(rng.choice([0, 1, 1, 2, 2, 3, 4]))):
+                q[pos] = (q[pos] + int(rng.integers(1, 4))) % 4
+            if rng.random() < 0.2:
+                q[int(rng.integers(0, qlen))] = 4
+            if rng.random() < 0.15 and qlen > 12:
+                cut = int(rng.integers(3, qlen - 3)); k = int(rng.integers(1, 4))
+                q = np.concatenate([q[:cut], q[cut + k:]]) if rng.random() < 0.5 else np.concatenate([q[:cut], rng.integers(0, 4, size=k, dtype=np.uint8), q[cut:]])
+                qlen = len(q)
+            h0 = int(rng.integers(19, 130)); w = int(rng.choice([100, 100, 200, 9])); zdrop = int(rng.choice([100, 100, 10])); end_bonus = 5
         opts = B.set_opt(bytearray(base_opts), **kw)
         mat = []
         for i in range(4):
             mat += [kw["a"] if i == j else -kw["b"] for j in range(4)] + [-1]
         mat += [-1] * 5
         B.set_opt(opts, mat=mat)
-        w = int(rng.choice([100, 200, 5, 1])); zdrop = int(rng.choice([100, 0, 10])); end_bonus = int(rng.choice([5, 0])); h0 = int(rng.integers(0, 150))
         want = (ctypes.c_int * 5)()
         ws = oext(qlen, q.tobytes(), tlen, t.tobytes(), 5, bytes(opts[140:165]), kw["o_del"], kw["e_del"], kw["o_ins"], kw["e_ins"], w, end_bonus, zdrop, h0,
                   ctypes.byref(want, 0), ctypes.byref(want, 4), ctypes.byref(want, 8), ctypes.byref(want, 12), ctypes.byref(want, 16))
-        got = (ctypes.c_int * 6)()
+        got = (ctypes.c_int * 7)()
         ob = ctypes.create_string_buffer(bytes(opts), 168)
-        for force_lds in (0, 1):          # the register-resident form (when the query fits) and the general LDS form
+        for force_lds in (0, 1, 2, 3):    # the register-resident form (when the query fits), the general LDS form, the production entry (diagonal
+                                          # certificate first), and the group form's band-limited DP (exact whenever it accepts the job)
             assert units.unit_extend(q.tobytes(), qlen, t.tobytes(), tlen, ob, w, end_bonus, zdrop, h0, got, force_lds) == 0
-            assert list(got) == [ws, want[0], want[1], want[2], want[3], want[4]], (it, force_lds, qlen, tlen, kw, w, zdrop, h0)
+            if force_lds == 3:
+                n_band[0] += 1; n_band[1] += got[6]
+                if not got[6]:
+                    continue
+            assert list(got)[:6] == [ws, want[0], want[1], want[2], want[3], want[4]], (it, force_lds, qlen, tlen, kw, w, zdrop, h0)
+    assert n_band[1] * 4 >= n_band[0], "the band form accepted only %d of %d jobs: the fixture does not exercise it" % (n_band[1], n_band[0])
 
 
 def test_units_emu_sort(oracle):
