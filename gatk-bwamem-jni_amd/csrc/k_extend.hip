@@ -407,36 +407,37 @@ static __device__ bool extend_diag(const DevIndex& ix, const MemOpt& opt, const 
 // band cell as long as the row keeps a live tail beyond the band, i.e. P_i > oe + (K+1) e for both gap kinds (checked);
 // its band w must cover ours (checked); rows past qlen + K cannot change any output.  Extensions that fail a check make
 // the read fall back to the one-read-per-wave kernel below it in the launch (k_extend<false>): same results either way.
-#define BAND_K 7
+#define BAND_NB 3                                               // up to three 16-lane chunks of diagonals: |j - i| <= 8 nb - 1
 struct GrpLds { uint8_t* query; uint8_t* target; };
+#ifndef BAND_TRACE
+#define BAND_TRACE 0
+#endif
+#define BAND_FAIL(code) do { if (BAND_TRACE && gl == 0) printf("[band] fail %d qlen=%d h0=%d deficit=%d pmin=%d\n", code, qlen, h0, deficit, p_min); return false; } while (0)
 
 static __device__ bool extend_band(const DevIndex& ix, const MemOpt& opt, const GrpLds& L, const int gl,
                                    int qlen, int q0, int qstep, int tlen, int64_t t0, int tstep,
                                    int w, int end_bonus, int zdrop, int h0, unsigned long long& n_cells, ExtRes& r)
 {
-    const int K = BAND_K;
     const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     if (h0 < 0) h0 = 0;
-    if (tlen < qlen || qlen <= 0 || qlen > 250 || h0 <= 0) return false;
+    int run = h0, dmax = h0, dmax_i = -1, deficit = 0, p_min = h0;
+    if (tlen < qlen || qlen <= 0 || qlen > 250 || h0 <= 0) BAND_FAIL(4);
     const int mx = score_max(opt);
-    {   // upstream's band after clipping by the longest affordable gap must cover ours
+    {   // upstream's band after clipping by the longest affordable gap
         int max_ins = div_plus(qlen * mx + end_bonus - o_ins, e_ins, 1), max_del = div_plus(qlen * mx + end_bonus - o_del, e_del, 1);
         max_ins = max_ins > 1 ? max_ins : 1; max_del = max_del > 1 ? max_del : 1;
         w = w < max_ins ? w : max_ins; w = w < max_del ? w : max_del;
-        if (w < K + 1) return false;
     }
     const ScoreTab ST = score_tab(opt);
-    const int n_rows = tlen < qlen + K ? tlen : qlen + K;
+    const int rows_max = tlen < qlen + 8 * BAND_NB ? tlen : qlen + 8 * BAND_NB;
     row_sync();                                                 // earlier readers of the target buffer are done
-    for (int i = gl; i < n_rows; i += GROUP) L.target[i] = (uint8_t)ref_base2(ix, t0 + (int64_t)tstep * i);
+    for (int i = gl; i < rows_max; i += GROUP) L.target[i] = (uint8_t)ref_base2(ix, t0 + (int64_t)tstep * i);
     row_sync();
     // ---- the diagonal: deficit, prefix scores, and the whole answer when nothing but the diagonal can matter
     const int g1 = oe_del < oe_ins ? oe_del : oe_ins;
     const int o_min = o_del < o_ins ? o_del : o_ins, e_min = e_del < e_ins ? e_del : e_ins;
-    const int d_max = o_min + (K + 1) * e_min;                  // deficits below this keep every out-of-band path irrelevant
-    int tail_min = oe_ins + (K + 1) * e_ins; { const int t2 = oe_del + (K + 1) * e_del; tail_min = (tail_min > t2 ? tail_min : t2) + 1; }
-    int run = h0, dmax = h0, dmax_i = -1, deficit = 0, p_min = h0;
+    const int d_lim = w < 8 * BAND_NB - 1 ? 0x3fffffff : o_min + 8 * BAND_NB * e_min;   // (when upstream's own band is the narrower one no path leaves it)
     bool z_ok = true;
     for (int c = 0; c < qlen; c += GROUP) {
         const int j = c + gl;
@@ -444,7 +445,7 @@ static __device__ bool extend_band(const DevIndex& ix, const MemOpt& opt, const 
         int sc = 0;
         if (act) { uint32_t p; int n; score_lane(ST, L.query[q0 + qstep * j], p, n); sc = score_at(p, n, L.target[j]); }
         deficit += row_all_sum(act ? mx - sc : 0);
-        if (deficit >= d_max || deficit >= h0) return false;
+        if (deficit >= d_lim || deficit >= h0) BAND_FAIL(deficit >= d_lim ? 1 : 2);
         const int P = run + row_prefix_sum(sc);
         const int pm = row_prefix_max(act ? P : NEG_INF_I32);
         int before = row_shr1(pm, NEG_INF_I32);
@@ -460,45 +461,71 @@ static __device__ bool extend_band(const DevIndex& ix, const MemOpt& opt, const 
         r.score = dmax; r.qle = dmax_i + 1; r.tle = dmax_i + 1; r.gtle = qlen; r.gscore = run; r.max_off = 0;
         return true;
     }
-    if (p_min < tail_min) return false;
-    // ---- the band.  Lane gl owns diagonal d = gl - 8 (gl = 0 is outside the band): column j = i + d at row i.
-    const int d = gl - 8;
-    int Hp, Ec = 0;                                             // eh[j].h = H(i-1, j-1) and eh[j].e = E(i, j) of the lane's cell
-    {
-        const int j = d;                                        // row 0
-        Hp = j == 0 ? h0 : j >= 1 && j <= qlen ? h0 - oe_ins - (j - 1) * e_ins : 0;
-        Hp = Hp > 0 ? Hp : 0;
+    // ---- the band: the narrowest that keeps every path outside it irrelevant, never wider than upstream's own
+    int K = 0;
+    while (deficit >= o_min + (K + 1) * e_min) ++K;
+    K = K < w ? K : w;
+    const int nb = (K + 8) >> 3;                                // chunks of 16 diagonals; diagonals |d| <= Kv are live
+    if (nb > BAND_NB) BAND_FAIL(1);
+    const int Kv = 8 * nb - 1 < w ? 8 * nb - 1 : w;
+    {   // upstream's window must keep a live tail beyond our band (or end at its own band / the query's end): see above
+        int tail_min = oe_ins + (Kv + 1) * e_ins; const int t2 = oe_del + (Kv + 1) * e_del;
+        tail_min = (tail_min > t2 ? tail_min : t2) + 1;
+        if (p_min < tail_min) BAND_FAIL(3);
+    }
+    const int c0 = 8 * nb;                                      // band index of the seed's diagonal: index b = cb * 16 + gl, d = b - c0
+    int Hp[BAND_NB], Ec[BAND_NB];                               // eh[j].h = H(i-1, j-1) and eh[j].e = E(i, j) of the lane's cells
+#pragma unroll
+    for (int cb = 0; cb < BAND_NB; ++cb) {
+        const int j = cb * 16 + gl - c0;                        // row 0
+        int v = j == 0 ? h0 : j >= 1 && j <= qlen ? h0 - oe_ins - (j - 1) * e_ins : 0;
+        Hp[cb] = v > 0 ? v : 0; Ec[cb] = 0;
     }
     int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
-    const int ge = gl * e_ins, gm1e = (gl - 1) * e_ins;
+    const int n_rows = tlen < qlen + Kv ? tlen : qlen + Kv;
     int i;
     for (i = 0; i < n_rows; ++i) {
-        const int j = i + d;
-        const bool inb = gl >= 1 && j >= 0 && j < qlen;
         const int tb = L.target[i];
-        int sc = 0;
-        if (inb) { uint32_t p; int n; score_lane(ST, L.query[q0 + qstep * j], p, n); sc = score_at(p, n, tb); }
-        const int M = inb && Hp ? Hp + sc : 0;
-        const int E = inb ? Ec : 0;
-        int T = M - oe_ins; T = T > 0 ? T : 0;
-        const int U = inb ? T + ge : NEG_INF_I32;
-        const int Pex = row_shr1(row_prefix_max(U), NEG_INF_I32);
-        int F = Pex - gm1e; F = F > 0 ? F : 0;
-        int h = M > E ? M : E; h = h > F ? h : F;
-        if (!inb) h = 0;
-        const int best = row_all_max(inb ? h << 8 | j : -1);   // row maximum with the last column that attains it
-        const int m = best < 0 ? 0 : best >> 8, mj = best < 0 ? -1 : best & 255;
-        n_cells += (unsigned long long)(best < 0 ? 0 : 1) * (unsigned long long)((i + K < qlen - 1 ? i + K : qlen - 1) - (i - K > 0 ? i - K : 0) + 1);
-        if (i >= qlen - 1 - K) {                                // the query's last column is in the band
-            const int hl = row_all_max(inb && j == qlen - 1 ? h : -1);
-            if (hl >= 0) { max_ie = gscore > hl ? max_ie : i; gscore = gscore > hl ? gscore : hl; }
+        int h1i = h0 - (o_del + e_del * (i + 1)); h1i = h1i > 0 ? h1i : 0;
+        int best = -1, hl = -1, fcarry = NEG_INF_I32;
+        int en[BAND_NB], hh[BAND_NB];
+#pragma unroll
+        for (int cb = 0; cb < BAND_NB; ++cb) {
+            en[cb] = 0; hh[cb] = 0;
+            if (cb < nb) {
+                const int b = cb * 16 + gl, d = b - c0, j = i + d;
+                const bool inb = d >= -Kv && d <= Kv && j >= 0 && j < qlen;
+                int sc = 0;
+                if (inb) { uint32_t p; int n; score_lane(ST, L.query[q0 + qstep * j], p, n); sc = score_at(p, n, tb); }
+                const int M = inb && Hp[cb] ? Hp[cb] + sc : 0;
+                const int E = inb ? Ec[cb] : 0;
+                int T = M - oe_ins; T = T > 0 ? T : 0;
+                const int U = inb ? T + b * e_ins : NEG_INF_I32;
+                const int P = row_prefix_max(U);
+                int F = row_shr1(P, NEG_INF_I32); F = F > fcarry ? F : fcarry;       // best T_k + k e over the columns to the left
+                F = F - (b - 1) * e_ins; F = F > 0 ? F : 0;
+                { const int tot = row_all_max(P); fcarry = fcarry > tot ? fcarry : tot; }
+                int h = M > E ? M : E; h = h > F ? h : F;
+                if (!inb) h = 0;
+                const int bk = row_all_max(inb ? h << 8 | j : -1);                   // row maximum with the last column that attains it
+                best = bk >= best ? bk : best;
+                if (i >= qlen - 1 - Kv) { const int x = row_all_max(inb && j == qlen - 1 ? h : -1); hl = hl > x ? hl : x; }
+                int t2 = M - oe_del; t2 = t2 > 0 ? t2 : 0;
+                int e2 = E - e_del; e2 = e2 > t2 ? e2 : t2;
+                en[cb] = inb ? e2 : 0;
+                hh[cb] = j == -1 && d >= -Kv ? h1i : h;                             // the first-column value stands in for H(i, -1)
+            }
         }
-        // next row: the first-column value stands in for H(i, -1); E(i+1, j) comes from the cell above = the lane to the right
-        int t2 = M - oe_del; t2 = t2 > 0 ? t2 : 0;
-        int en = E - e_del; en = en > t2 ? en : t2;
-        if (!inb) en = 0;
-        Ec = row_shl1(en, 0);
-        { int h1i = h0 - (o_del + e_del * (i + 1)); h1i = h1i > 0 ? h1i : 0; Hp = j == -1 && gl >= 1 ? h1i : h; }
+        // next row: H(i, j) stays on its diagonal; E(i+1, j) comes from the cell above = the next band index
+#pragma unroll
+        for (int cb = 0; cb < BAND_NB; ++cb) {
+            const int nxt = cb + 1 < BAND_NB ? __builtin_amdgcn_update_dpp(0, en[cb + 1 < BAND_NB ? cb + 1 : cb], DPP_ROW_SHR(15), 0xf, 0xf, false) : 0;   // lane 15 <- lane 0 of the next chunk
+            Ec[cb] = row_shl1(en[cb], cb + 1 < BAND_NB ? nxt : 0);
+            Hp[cb] = hh[cb];
+        }
+        const int m = best < 0 ? 0 : best >> 8, mj = best < 0 ? -1 : best & 255;
+        if (best >= 0) n_cells += (unsigned long long)((i + Kv < qlen - 1 ? i + Kv : qlen - 1) - (i - Kv > 0 ? i - Kv : 0) + 1);
+        if (hl >= 0) { max_ie = gscore > hl ? max_ie : i; gscore = gscore > hl ? gscore : hl; }
         if (m == 0) break;
         if (m > max) {
             max = m; max_i = i; max_j = mj;
@@ -512,6 +539,9 @@ static __device__ bool extend_band(const DevIndex& ix, const MemOpt& opt, const 
             }
         }
     }
+    // a loop that stopped (z-drop) before the diagonal reached the query's last column leaves upstream's to-end score to its
+    // far tails, which the band does not hold
+    if (i < qlen - 1 && i < n_rows) BAND_FAIL(6);
     r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
     return true;
 }
@@ -555,7 +585,7 @@ static __device__ __forceinline__ bool extend_read(const DevIndex& ix, const Mem
     GrpLds G;
     uint8_t* sq;
     bool aborted = false;
-    if (GW != WAVE) {                                           // smem: this group's slice, 256 bytes of read + 272 of target window
+    if (GW != WAVE) {                                           // smem: this group's slice, 256 bytes of read + 288 of target window
         sq = (uint8_t*)smem;
         G.query = sq; G.target = sq + 256;
         L.eh_h = L.eh_e = L.tmpM = nullptr;
@@ -742,11 +772,11 @@ __global__ void __launch_bounds__(64, K_EXTEND_MIN_WAVES) k_extend(DevIndex ix, 
 // the group form: four reads per wavefront (see extend_band); reads it cannot finish are appended to list
 __global__ void __launch_bounds__(64, K_EXTEND_GRP_MIN_WAVES) k_extend_grp(DevIndex ix, MemOpt opt, TileView tv, int32_t* list)
 {
-    __shared__ int32_t smem[4 * 132];                           // per row: 256 bytes of read + 272 of target window
+    __shared__ int32_t smem[4 * 136];                           // per row: 256 bytes of read + 288 of target window
     const int lane = threadIdx.x, g = lane >> 4;
     const int r = blockIdx.x * 4 + g;
     if (r >= tv.n_reads) return;
-    if (!extend_read<false, GROUP>(ix, opt, tv, smem + g * 132, r, lane) && (lane & 15) == 0)
+    if (!extend_read<false, GROUP>(ix, opt, tv, smem + g * 136, r, lane) && (lane & 15) == 0)
         list[1 + atomicAdd(list, 1)] = r;
 }
 

@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(64) k_unit_extend(DevIndex ix, MemOpt opt, con
     ExtRes r;
     int ok = 1;
     if (force_lds == 3) {                                       // the group form's band-limited DP: every 16-lane row runs the same job
-        __shared__ uint8_t tbuf[4][272];
+        __shared__ uint8_t tbuf[4][288];
         GrpLds G; G.query = sq; G.target = tbuf[lane >> 4];
         ok = extend_band(ix, opt, G, lane & 15, qlen, 0, 1, tlen, 0, 1, w, end_bonus, zdrop, h0, n_cells, r) ? 1 : 0;
         if (!ok) { r.score = r.qle = r.tle = r.gtle = r.gscore = r.max_off = 0; }
