@@ -407,7 +407,9 @@ static __device__ bool extend_diag(const DevIndex& ix, const MemOpt& opt, const 
 // band cell as long as the row keeps a live tail beyond the band, i.e. P_i > oe + (K+1) e for both gap kinds (checked);
 // its band w must cover ours (checked); rows past qlen + K cannot change any output.  Extensions that fail a check make
 // the read fall back to the one-read-per-wave kernel below it in the launch (k_extend<false>): same results either way.
-#define BAND_NB 3                                               // up to three 16-lane chunks of diagonals: |j - i| <= 8 nb - 1
+#ifndef BAND_NB
+#define BAND_NB 1                                               // 16-lane chunks of diagonals per row: |j - i| <= 8 BAND_NB - 1 (wider bands make the four rows of a wave wait for the widest)
+#endif
 struct GrpLds { uint8_t* query; uint8_t* target; };
 #ifndef BAND_TRACE
 #define BAND_TRACE 0
@@ -767,7 +769,7 @@ __global__ void __launch_bounds__(64, K_EXTEND_MIN_WAVES) k_extend(DevIndex ix, 
 }
 
 #ifndef K_EXTEND_GRP_MIN_WAVES
-#define K_EXTEND_GRP_MIN_WAVES 6
+#define K_EXTEND_GRP_MIN_WAVES 4
 #endif
 // the group form: four reads per wavefront (see extend_band); reads it cannot finish are appended to list
 __global__ void __launch_bounds__(64, K_EXTEND_GRP_MIN_WAVES) k_extend_grp(DevIndex ix, MemOpt opt, TileView tv, int32_t* list)
