@@ -165,6 +165,5 @@ struct TileView {
     int32_t* dp_rows;             // null: DP rows of k_extend / k_gcigar in LDS; else dp_rows_blocks slices of 3 x (max_len + 2) ints (very long reads)
     int32_t dp_rows_blocks;
     int32_t debug;                // BWAMEM_HIP_DEBUGK: device-side progress prints (debugging aid)
-    int32_t* ext_list;            // [1 + n_reads] reads handed from k_extend's group form to its one-read-per-wave form
     int32_t pad_;
 };

@@ -336,7 +336,7 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
     return r;
 }
 
-// The diagonal certificate: most extensions of well-placed reads run along the seed's diagonal with at most one mismatch,
+// The diagonal certificate: many extensions of well-placed reads run along the seed's diagonal with at most one mismatch,
 // and then the banded DP is decided before it starts.  Let s_j = mat[t_j][q_j] be the scores on the diagonal, a = max(mat),
 // D = sum_j (a - s_j) over the whole query (the "deficit") and g = min(o_del + e_del, o_ins + e_ins).  A path from the origin
 // to any cell of row i that opens a gap scores at most h0 + a (i+1) - g (n diagonal steps score <= a each, n <= i+1), while
@@ -393,161 +393,6 @@ static __device__ bool extend_diag(const DevIndex& ix, const MemOpt& opt, const 
     return true;
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// The group form: FOUR reads per wavefront, one per 16-lane DPP row, each row running mem_chain2aln's control flow for its
-// own read, with the extension DP confined to the 2K+1 = 15 diagonals around the seed's.
-//
-// Why that is exact.  With D = sum over the query of (a - s_jj) (the deficit of the seed's diagonal, a = max(mat)) and
-// P_i the ungapped prefix scores, any path that ever leaves the band |j - i| <= K pays at least o + (K+1) e in gaps
-// (o, e the smaller open / extend penalties) and collects at most a per diagonal step, so it scores below
-// h0 + a (i+1) - o - (K+1) e at row i, while P_i >= h0 + a (i+1) - D.  If D < o + (K+1) e, no cell that depends on an
-// out-of-band cell can be a row maximum, the best last-column cell, or tie with one: ksw_extend2's outputs are those of
-// the DP restricted to the band (cells outside dead), which this code computes with upstream's recurrence (gap opens from
-// M only, dead cells cannot restart, first-row and first-column decay from h0).  Upstream's window trimming never cuts a
-// band cell as long as the row keeps a live tail beyond the band, i.e. P_i > oe + (K+1) e for both gap kinds (checked);
-// its band w must cover ours (checked); rows past qlen + K cannot change any output.  Extensions that fail a check make
-// the read fall back to the one-read-per-wave kernel below it in the launch (k_extend<false>): same results either way.
-#ifndef BAND_NB
-#define BAND_NB 1                                               // 16-lane chunks of diagonals per row: |j - i| <= 8 BAND_NB - 1 (wider bands make the four rows of a wave wait for the widest)
-#endif
-struct GrpLds { uint8_t* query; uint8_t* target; };
-#ifndef BAND_TRACE
-#define BAND_TRACE 0
-#endif
-#define BAND_FAIL(code) do { if (BAND_TRACE && gl == 0) printf("[band] fail %d qlen=%d h0=%d deficit=%d pmin=%d\n", code, qlen, h0, deficit, p_min); return false; } while (0)
-
-static __device__ bool extend_band(const DevIndex& ix, const MemOpt& opt, const GrpLds& L, const int gl,
-                                   int qlen, int q0, int qstep, int tlen, int64_t t0, int tstep,
-                                   int w, int end_bonus, int zdrop, int h0, unsigned long long& n_cells, ExtRes& r)
-{
-    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
-    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    if (h0 < 0) h0 = 0;
-    int run = h0, dmax = h0, dmax_i = -1, deficit = 0, p_min = h0;
-    if (tlen < qlen || qlen <= 0 || qlen > 250 || h0 <= 0) BAND_FAIL(4);
-    const int mx = score_max(opt);
-    {   // upstream's band after clipping by the longest affordable gap
-        int max_ins = div_plus(qlen * mx + end_bonus - o_ins, e_ins, 1), max_del = div_plus(qlen * mx + end_bonus - o_del, e_del, 1);
-        max_ins = max_ins > 1 ? max_ins : 1; max_del = max_del > 1 ? max_del : 1;
-        w = w < max_ins ? w : max_ins; w = w < max_del ? w : max_del;
-    }
-    const ScoreTab ST = score_tab(opt);
-    const int rows_max = tlen < qlen + 8 * BAND_NB ? tlen : qlen + 8 * BAND_NB;
-    row_sync();                                                 // earlier readers of the target buffer are done
-    for (int i = gl; i < rows_max; i += GROUP) L.target[i] = (uint8_t)ref_base2(ix, t0 + (int64_t)tstep * i);
-    row_sync();
-    // ---- the diagonal: deficit, prefix scores, and the whole answer when nothing but the diagonal can matter
-    const int g1 = oe_del < oe_ins ? oe_del : oe_ins;
-    const int o_min = o_del < o_ins ? o_del : o_ins, e_min = e_del < e_ins ? e_del : e_ins;
-    const int d_lim = w < 8 * BAND_NB - 1 ? 0x3fffffff : o_min + 8 * BAND_NB * e_min;   // (when upstream's own band is the narrower one no path leaves it)
-    bool z_ok = true;
-    for (int c = 0; c < qlen; c += GROUP) {
-        const int j = c + gl;
-        const bool act = j < qlen;
-        int sc = 0;
-        if (act) { uint32_t p; int n; score_lane(ST, L.query[q0 + qstep * j], p, n); sc = score_at(p, n, L.target[j]); }
-        deficit += row_all_sum(act ? mx - sc : 0);
-        if (deficit >= d_lim || deficit >= h0) BAND_FAIL(deficit >= d_lim ? 1 : 2);
-        const int P = run + row_prefix_sum(sc);
-        const int pm = row_prefix_max(act ? P : NEG_INF_I32);
-        int before = row_shr1(pm, NEG_INF_I32);
-        before = before > dmax ? before : dmax;
-        if (zdrop > 0 && row_all_max(act && P <= before && before - P > zdrop ? 1 : 0)) z_ok = false;
-        const int lo = -row_all_max(act ? -P : NEG_INF_I32);
-        p_min = p_min < lo ? p_min : lo;
-        const int cm = row_all_max(act ? P : NEG_INF_I32);
-        if (cm > dmax) { dmax = cm; dmax_i = c + 15 - row_all_max(act && P == cm ? 15 - gl : -1); }     // first column attaining it
-        run = row_all_max(gl == GROUP - 1 ? P : NEG_INF_I32);  // lanes past the query repeat the last prefix
-    }
-    if (deficit < g1 && z_ok) {                                // see extend_diag(): decided by the diagonal alone
-        r.score = dmax; r.qle = dmax_i + 1; r.tle = dmax_i + 1; r.gtle = qlen; r.gscore = run; r.max_off = 0;
-        return true;
-    }
-    // ---- the band: the narrowest that keeps every path outside it irrelevant, never wider than upstream's own
-    int K = 0;
-    while (deficit >= o_min + (K + 1) * e_min) ++K;
-    K = K < w ? K : w;
-    const int nb = (K + 8) >> 3;                                // chunks of 16 diagonals; diagonals |d| <= Kv are live
-    if (nb > BAND_NB) BAND_FAIL(1);
-    const int Kv = 8 * nb - 1 < w ? 8 * nb - 1 : w;
-    {   // upstream's window must keep a live tail beyond our band (or end at its own band / the query's end): see above
-        int tail_min = oe_ins + (Kv + 1) * e_ins; const int t2 = oe_del + (Kv + 1) * e_del;
-        tail_min = (tail_min > t2 ? tail_min : t2) + 1;
-        if (p_min < tail_min) BAND_FAIL(3);
-    }
-    const int c0 = 8 * nb;                                      // band index of the seed's diagonal: index b = cb * 16 + gl, d = b - c0
-    int Hp[BAND_NB], Ec[BAND_NB];                               // eh[j].h = H(i-1, j-1) and eh[j].e = E(i, j) of the lane's cells
-#pragma unroll
-    for (int cb = 0; cb < BAND_NB; ++cb) {
-        const int j = cb * 16 + gl - c0;                        // row 0
-        int v = j == 0 ? h0 : j >= 1 && j <= qlen ? h0 - oe_ins - (j - 1) * e_ins : 0;
-        Hp[cb] = v > 0 ? v : 0; Ec[cb] = 0;
-    }
-    int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
-    const int n_rows = tlen < qlen + Kv ? tlen : qlen + Kv;
-    int i;
-    for (i = 0; i < n_rows; ++i) {
-        const int tb = L.target[i];
-        int h1i = h0 - (o_del + e_del * (i + 1)); h1i = h1i > 0 ? h1i : 0;
-        int best = -1, hl = -1, fcarry = NEG_INF_I32;
-        int en[BAND_NB], hh[BAND_NB];
-#pragma unroll
-        for (int cb = 0; cb < BAND_NB; ++cb) {
-            en[cb] = 0; hh[cb] = 0;
-            if (cb < nb) {
-                const int b = cb * 16 + gl, d = b - c0, j = i + d;
-                const bool inb = d >= -Kv && d <= Kv && j >= 0 && j < qlen;
-                int sc = 0;
-                if (inb) { uint32_t p; int n; score_lane(ST, L.query[q0 + qstep * j], p, n); sc = score_at(p, n, tb); }
-                const int M = inb && Hp[cb] ? Hp[cb] + sc : 0;
-                const int E = inb ? Ec[cb] : 0;
-                int T = M - oe_ins; T = T > 0 ? T : 0;
-                const int U = inb ? T + b * e_ins : NEG_INF_I32;
-                const int P = row_prefix_max(U);
-                int F = row_shr1(P, NEG_INF_I32); F = F > fcarry ? F : fcarry;       // best T_k + k e over the columns to the left
-                F = F - (b - 1) * e_ins; F = F > 0 ? F : 0;
-                { const int tot = row_all_max(P); fcarry = fcarry > tot ? fcarry : tot; }
-                int h = M > E ? M : E; h = h > F ? h : F;
-                if (!inb) h = 0;
-                const int bk = row_all_max(inb ? h << 8 | j : -1);                   // row maximum with the last column that attains it
-                best = bk >= best ? bk : best;
-                if (i >= qlen - 1 - Kv) { const int x = row_all_max(inb && j == qlen - 1 ? h : -1); hl = hl > x ? hl : x; }
-                int t2 = M - oe_del; t2 = t2 > 0 ? t2 : 0;
-                int e2 = E - e_del; e2 = e2 > t2 ? e2 : t2;
-                en[cb] = inb ? e2 : 0;
-                hh[cb] = j == -1 && d >= -Kv ? h1i : h;                             // the first-column value stands in for H(i, -1)
-            }
-        }
-        // next row: H(i, j) stays on its diagonal; E(i+1, j) comes from the cell above = the next band index
-#pragma unroll
-        for (int cb = 0; cb < BAND_NB; ++cb) {
-            const int nxt = cb + 1 < BAND_NB ? __builtin_amdgcn_update_dpp(0, en[cb + 1 < BAND_NB ? cb + 1 : cb], DPP_ROW_SHR(15), 0xf, 0xf, false) : 0;   // lane 15 <- lane 0 of the next chunk
-            Ec[cb] = row_shl1(en[cb], cb + 1 < BAND_NB ? nxt : 0);
-            Hp[cb] = hh[cb];
-        }
-        const int m = best < 0 ? 0 : best >> 8, mj = best < 0 ? -1 : best & 255;
-        if (best >= 0) n_cells += (unsigned long long)((i + Kv < qlen - 1 ? i + Kv : qlen - 1) - (i - Kv > 0 ? i - Kv : 0) + 1);
-        if (hl >= 0) { max_ie = gscore > hl ? max_ie : i; gscore = gscore > hl ? gscore : hl; }
-        if (m == 0) break;
-        if (m > max) {
-            max = m; max_i = i; max_j = mj;
-            int df = mj - i; df = df < 0 ? -df : df;
-            max_off = max_off > df ? max_off : df;
-        } else if (zdrop > 0) {
-            if (i - max_i > mj - max_j) {
-                if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
-            } else {
-                if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
-            }
-        }
-    }
-    // a loop that stopped (z-drop) before the diagonal reached the query's last column leaves upstream's to-end score to its
-    // far tails, which the band does not hold
-    if (i < qlen - 1 && i < n_rows) BAND_FAIL(6);
-    r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
-    return true;
-}
-
 // picks the register-resident form when the query fits
 static __device__ ExtRes extend_any(const DevIndex& ix, const MemOpt& opt, const ExtLds& L, int lane,
                                     int qlen, int q0, int qstep, int tlen, int64_t t0, int tstep,
@@ -572,27 +417,15 @@ struct U64Lt { __device__ bool operator()(uint64_t a, uint64_t b) const { return
 // HBM = false: one workgroup per read, the rows of the general DP form in LDS (every read up to ~12 000 bases).
 // HBM = true: reads whose rows do not fit a CU's LDS -- a bounded grid walks the reads and each workgroup keeps its rows in
 // its own slice of tv.dp_rows (global memory; only the read itself stays in LDS).  Same code, same results, slower rows.
-// GW = 64: one read per wavefront (every DP form).  GW = 16: the group form -- this read runs on one 16-lane row of the
-// wave while the other rows run other reads; extensions go through extend_band, and the first one that fails its
-// checks abandons the read to the GW = 64 kernel (returns false; nothing the read has written so far is kept).
-#define GSYNC() do { if (GW == WAVE) __syncthreads(); else row_sync(); } while (0)
-template <bool HBM, int GW>
-static __device__ __forceinline__ bool extend_read(const DevIndex& ix, const MemOpt& opt, const TileView& tv, int32_t* smem, const int r, const int lane_)
+template <bool HBM>
+static __device__ __forceinline__ void extend_read(const DevIndex& ix, const MemOpt& opt, const TileView& tv, int32_t* smem, const int r, const int lane)
 {
-    const int lane = lane_ & (GW - 1);                          // position within the group that owns the read
     const int64_t s0 = tv.seed_off[r];
     const int l_query = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
     const int cap = tv.max_len + 2;
     ExtLds L;
-    GrpLds G;
     uint8_t* sq;
-    bool aborted = false;
-    if (GW != WAVE) {                                           // smem: this group's slice, 256 bytes of read + 288 of target window
-        sq = (uint8_t*)smem;
-        G.query = sq; G.target = sq + 256;
-        L.eh_h = L.eh_e = L.tmpM = nullptr;
-        if (l_query > 250) return false;
-    } else if (HBM) {
+    if (HBM) {
         int32_t* rows = tv.dp_rows + (size_t)blockIdx.x * 3 * (size_t)cap;
         L.eh_h = rows; L.eh_e = rows + cap; L.tmpM = rows + 2 * cap;
         sq = (uint8_t*)smem;
@@ -602,8 +435,8 @@ static __device__ __forceinline__ bool extend_read(const DevIndex& ix, const Mem
         L.eh_h = rows; L.eh_e = rows + cap; L.tmpM = rows + 2 * cap;
     }
     L.query = sq;
-    for (int j = lane; j < l_query; j += GW) sq[j] = tv.seq[tv.seq_off[r] + j];
-    GSYNC();
+    for (int j = lane; j < l_query; j += WAVE) sq[j] = tv.seq[tv.seq_off[r] + j];
+    __syncthreads();
 
     const int n_chn = tv.n_chains[r];
     const Chain* chains = tv.chains + s0;
@@ -638,7 +471,7 @@ static __device__ __forceinline__ bool extend_read(const DevIndex& ix, const Mem
             for (int i = 0; i < c.n; ++i) srt[i] = (uint64_t)(uint32_t)seeds[i].score << 32 | (uint32_t)i;
             ks_introsort((size_t)c.n, srt, U64Lt());
         }
-        GSYNC();
+        __syncthreads();
 
         for (int k = c.n - 1; k >= 0; --k) {
             const Seed s = seeds[(uint32_t)srt[k]];
@@ -666,9 +499,9 @@ static __device__ __forceinline__ bool extend_read(const DevIndex& ix, const Mem
                     if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) break;
                 }
                 if (i == c.n) {
-                    GSYNC();
+                    __syncthreads();
                     if (lane == 0) srt[k] = 0;
-                    GSYNC();
+                    __syncthreads();
                     continue;
                 }
             }
@@ -687,14 +520,11 @@ static __device__ __forceinline__ bool extend_read(const DevIndex& ix, const Mem
                 for (i = 0; i < MAX_BAND_TRY; ++i) {
                     int prev = a.score;
                     aw0 = opt.w << i;
-                    if (GW == WAVE) e = extend_any(ix, opt, L, lane, s.qbeg, s.qbeg - 1, -1, (int)tmp, s.rbeg - 1, -1,
-                                                   aw0, opt.pen_clip5, opt.zdrop, s.len * opt.a, n_cells, try_diag);
-                    else if (!extend_band(ix, opt, G, lane, s.qbeg, s.qbeg - 1, -1, (int)tmp, s.rbeg - 1, -1,
-                                          aw0, opt.pen_clip5, opt.zdrop, s.len * opt.a, n_cells, e)) { aborted = true; break; }
+                    e = extend_any(ix, opt, L, lane, s.qbeg, s.qbeg - 1, -1, (int)tmp, s.rbeg - 1, -1,
+                                    aw0, opt.pen_clip5, opt.zdrop, s.len * opt.a, n_cells, try_diag);
                     a.score = e.score;
                     if (a.score == prev || e.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
                 }
-                if (aborted) break;
                 if (e.gscore <= 0 || e.gscore <= a.score - opt.pen_clip5) {
                     a.qb = s.qbeg - e.qle; a.rb = s.rbeg - e.tle;
                     a.truesc = a.score;
@@ -711,14 +541,11 @@ static __device__ __forceinline__ bool extend_read(const DevIndex& ix, const Mem
                 for (i = 0; i < MAX_BAND_TRY; ++i) {
                     int prev = a.score;
                     aw1 = opt.w << i;
-                    if (GW == WAVE) e = extend_any(ix, opt, L, lane, l_query - qe, qe, 1, (int)(rmax1 - rmax0 - re), rmax0 + re, 1,
-                                                   aw1, opt.pen_clip3, opt.zdrop, sc0, n_cells, try_diag);
-                    else if (!extend_band(ix, opt, G, lane, l_query - qe, qe, 1, (int)(rmax1 - rmax0 - re), rmax0 + re, 1,
-                                          aw1, opt.pen_clip3, opt.zdrop, sc0, n_cells, e)) { aborted = true; break; }
+                    e = extend_any(ix, opt, L, lane, l_query - qe, qe, 1, (int)(rmax1 - rmax0 - re), rmax0 + re, 1,
+                                    aw1, opt.pen_clip3, opt.zdrop, sc0, n_cells, try_diag);
                     a.score = e.score;
                     if (a.score == prev || e.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
                 }
-                if (aborted) break;
                 if (e.gscore <= 0 || e.gscore <= a.score - opt.pen_clip3) {
                     a.qe = qe + e.qle; a.re = rmax0 + re + e.tle;
                     a.truesc += a.score - sc0;
@@ -737,49 +564,27 @@ static __device__ __forceinline__ bool extend_read(const DevIndex& ix, const Mem
             a.w = aw0 > aw1 ? aw0 : aw1;
             a.seedlen0 = s.len;
             a.frac_rep = c.frac_rep;
-            GSYNC();
+            __syncthreads();
             if (lane == 0) regs[n_regs] = a;
             ++n_regs;
-            GSYNC();
+            __syncthreads();
         }
-        if (aborted) break;
     }
     if (lane == 0) {
-        if (!aborted) tv.n_regs[r] = n_regs;
+        tv.n_regs[r] = n_regs;
         count_add(&tv.cnt->n_dp_cells, n_cells);
     }
-    return !aborted;
 }
 
-// list != null: only the reads the group kernel abandoned (list[0] = their number, list[1..] = the reads)
 template <bool HBM>
-__global__ void __launch_bounds__(64, K_EXTEND_MIN_WAVES) k_extend(DevIndex ix, MemOpt opt, TileView tv, const int32_t* list)
+__global__ void __launch_bounds__(64, K_EXTEND_MIN_WAVES) k_extend(DevIndex ix, MemOpt opt, TileView tv)
 {
     HIP_DYNAMIC_SHARED(int32_t, smem)
-    if (!HBM) {
-        int r = blockIdx.x;
-        if (list) { if (r >= list[0]) return; r = list[1 + r]; }
-        extend_read<false, WAVE>(ix, opt, tv, smem, r, threadIdx.x);
-        return;
-    }
+    if (!HBM) { extend_read<false>(ix, opt, tv, smem, blockIdx.x, threadIdx.x); return; }
     for (int r = blockIdx.x; r < tv.n_reads; r += (int)gridDim.x) {
-        extend_read<true, WAVE>(ix, opt, tv, smem, r, threadIdx.x);
+        extend_read<true>(ix, opt, tv, smem, r, threadIdx.x);
         __syncthreads();                                        // the next read reuses the rows and the staged query
     }
-}
-
-#ifndef K_EXTEND_GRP_MIN_WAVES
-#define K_EXTEND_GRP_MIN_WAVES 4
-#endif
-// the group form: four reads per wavefront (see extend_band); reads it cannot finish are appended to list
-__global__ void __launch_bounds__(64, K_EXTEND_GRP_MIN_WAVES) k_extend_grp(DevIndex ix, MemOpt opt, TileView tv, int32_t* list)
-{
-    __shared__ int32_t smem[4 * 136];                           // per row: 256 bytes of read + 288 of target window
-    const int lane = threadIdx.x, g = lane >> 4;
-    const int r = blockIdx.x * 4 + g;
-    if (r >= tv.n_reads) return;
-    if (!extend_read<false, GROUP>(ix, opt, tv, smem + g * 136, r, lane) && (lane & 15) == 0)
-        list[1 + atomicAdd(list, 1)] = r;
 }
 
 // LDS of one k_extend workgroup for reads of up to max_len bases: the H, E and M rows of the general form + the read
@@ -794,19 +599,11 @@ void launch_extend(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const 
     if (tv.dp_rows) {                                           // rows in global memory: tv.dp_rows_blocks slices of 3 x (max_len + 2) ints
         const size_t cap = (size_t)tv.max_len + 2;
         const int grid = tv.n_reads < tv.dp_rows_blocks ? tv.n_reads : tv.dp_rows_blocks;
-        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(64), (cap + 15) & ~(size_t)15, st, ix, opt, tv, (const int32_t*)nullptr);
+        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(64), (cap + 15) & ~(size_t)15, st, ix, opt, tv);
         return;
     }
     // every query of a tile whose reads are at most 3 * 64 - 1 bases long takes the register form: no rows in LDS, only the
     // read -- which matters for overlap, because k_seed fills the CUs' LDS and a workgroup that asks for 2 KB finds no room
     size_t shmem = tv.max_len + 1 <= 3 * WAVE ? (((size_t)tv.max_len + 2 + 15) & ~(size_t)15) : extend_lds_bytes(tv.max_len);
-    // reads of up to 250 bases: four per wavefront first (band-limited DP, exact where its checks pass), then the reads that
-    // form gave up on, one per wavefront.  BWAMEM_HIP_DEBUGK=512: the one-read-per-wave kernel for everything.
-    if (tv.max_len <= 250 && tv.ext_list && !(tv.debug & 0x200)) {
-        (void)hipMemsetAsync(tv.ext_list, 0, 4, st);
-        hipLaunchKernelGGL(k_extend_grp, dim3((tv.n_reads + 3) / 4), dim3(64), 0, st, ix, opt, tv, tv.ext_list);
-        hipLaunchKernelGGL(k_extend<false>, dim3(tv.n_reads), dim3(64), shmem, st, ix, opt, tv, (const int32_t*)tv.ext_list);
-        return;
-    }
-    hipLaunchKernelGGL(k_extend<false>, dim3(tv.n_reads), dim3(64), shmem, st, ix, opt, tv, (const int32_t*)nullptr);
+    hipLaunchKernelGGL(k_extend<false>, dim3(tv.n_reads), dim3(64), shmem, st, ix, opt, tv);
 }

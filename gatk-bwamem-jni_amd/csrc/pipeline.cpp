@@ -86,7 +86,7 @@ struct Workspace {
     int job_cap = 0, job_cig_cap = 0; size_t zpool_cap = 0;
     int out_cap_hint = 512;                           // bytes per read of the output staging slots (grown on overflow, kept across tiles)
     int dev_lds = 0;                                  // LDS per workgroup of the device this workspace lives on
-    DevBuf scan_tmp, packed, ext_list;                        // block sums of the multi-block scan; the tile's packed records on their way to the host
+    DevBuf scan_tmp, packed;                          // block sums of the multi-block scan; the tile's packed records on their way to the host
     DevBuf pe_dir, pe_is, pe_caps, pe_reg_off2, pe_regs2, pe_ints2, pe_vpool, pe_scratch, pe_states, pe_rescue[3];   // paired-end stages
     hipStream_t stream = nullptr;
     std::vector<Timed> timed;
@@ -103,7 +103,7 @@ struct Workspace {
             dp_rows_blocks = (int)std::min<size_t>(4096, std::max<size_t>(256, ((size_t)2 << 30) / per_block));
             if (!dp_rows.ensure((size_t)dp_rows_blocks * per_block)) return false;
         }
-        return seed_off.ensure((t + 1) * 8) && scan_tmp.ensure(scan_tmp_bytes((int64_t)t + 1)) && ext_list.ensure((t + 2) * 4)
+        return seed_off.ensure((t + 1) * 8) && scan_tmp.ensure(scan_tmp_bytes((int64_t)t + 1))
             && n_chains.ensure(t * 4) && n_regs.ensure(t * 4) && out.ensure(t * out_cap) && out_len.ensure(t * 4)
             && out_off.ensure((t + 1) * 8) && post.ensure(t * (size_t)post_per_read) && err.ensure(64) && cnt.ensure(sizeof(DevCounters));
     }
@@ -123,7 +123,7 @@ struct Workspace {
         DevBuf* all[] = { &intv, &n_intv, &smem, &l_rep, &n_seeds, &seed_off, &intv_seed_off, &seeds, &seed_rid, &cseeds, &chains,
                           &chain_store, &n_chains, &bt_nodes, &srt, &regs, &n_regs, &out, &out_len, &out_off, &post, &err, &cnt, &dp_rows,
                           &jobs, &job_out, &job_cig, &job_cnt, &zpool, &pe_dir, &pe_is, &pe_caps, &pe_reg_off2, &pe_regs2, &pe_ints2, &pe_vpool, &pe_scratch, &pe_states,
-                          &pe_rescue[0], &pe_rescue[1], &pe_rescue[2], &scan_tmp, &packed, &ext_list };
+                          &pe_rescue[0], &pe_rescue[1], &pe_rescue[2], &scan_tmp, &packed };
         for (DevBuf* b : all) b->release();
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     }
@@ -141,7 +141,6 @@ struct Workspace {
         tv.dp_rows = dp_rows_blocks ? dp_rows.as<int32_t>() : nullptr; tv.dp_rows_blocks = dp_rows_blocks;
         tv.job_cnt = job_cnt.as<int32_t>(); tv.jobs = jobs.p; tv.job_cap = job_cap;
         tv.smem_groups = (T + 63) / 64;
-        tv.ext_list = ext_list.as<int32_t>();
         { const char* e = getenv("BWAMEM_HIP_DEBUGK"); tv.debug = e ? atoi(e) : 0; }
         return tv;
     }

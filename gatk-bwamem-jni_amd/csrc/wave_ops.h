@@ -57,54 +57,3 @@ static __device__ inline int dpp_shr1(int v, int fill) { return __builtin_amdgcn
 static __device__ inline int dpp_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHL1, 0xf, 0xf, false); }
 // value of a (wave-uniform) lane as a scalar
 static __device__ inline int wave_readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-
-// ---- 16-lane groups ("rows" of the DPP network): collectives that stay inside a row, usable where the four rows of a wave
-// run different control flow (k_extend's group form).  Row-local DPP controls: row_shr:n, row_shl:n = 0x100+n,
-// quad_perm = 0x00..0xff, row_mirror = 0x140, row_half_mirror = 0x141.
-#define GROUP 16
-#define DPP_ROW_SHL(n) (0x100 + (n))
-#define DPP_QUAD_PERM(a, b, c, d) ((a) | (b) << 2 | (c) << 4 | (d) << 6)
-#define DPP_ROW_MIRROR 0x140
-#define DPP_ROW_HALF_MIRROR 0x141
-
-static __device__ inline int row_prefix_max(int v)            // inclusive, over the lanes of the row
-{
-    const int id = (int)0x80000000;
-    int t;
-    t = __builtin_amdgcn_update_dpp(id, v, DPP_ROW_SHR(1), 0xf, 0xf, false); v = v > t ? v : t;
-    t = __builtin_amdgcn_update_dpp(id, v, DPP_ROW_SHR(2), 0xf, 0xf, false); v = v > t ? v : t;
-    t = __builtin_amdgcn_update_dpp(id, v, DPP_ROW_SHR(4), 0xf, 0xf, false); v = v > t ? v : t;
-    t = __builtin_amdgcn_update_dpp(id, v, DPP_ROW_SHR(8), 0xf, 0xf, false); v = v > t ? v : t;
-    return v;
-}
-static __device__ inline int row_prefix_sum(int v)            // inclusive
-{
-    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(1), 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(2), 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(4), 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(8), 0xf, 0xf, false);
-    return v;
-}
-// lane l <- lane l-1 of the row (first lane <- fill); lane l <- lane l+1 (last lane <- fill)
-static __device__ inline int row_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, DPP_ROW_SHR(1), 0xf, 0xf, false); }
-static __device__ inline int row_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, DPP_ROW_SHL(1), 0xf, 0xf, false); }
-// butterfly over the 16 lanes: every lane ends up with the row's maximum / sum
-static __device__ inline int row_all_max(int v)
-{
-    int t;
-    t = __builtin_amdgcn_update_dpp(v, v, DPP_QUAD_PERM(1, 0, 3, 2), 0xf, 0xf, false); v = v > t ? v : t;
-    t = __builtin_amdgcn_update_dpp(v, v, DPP_QUAD_PERM(2, 3, 0, 1), 0xf, 0xf, false); v = v > t ? v : t;
-    t = __builtin_amdgcn_update_dpp(v, v, DPP_ROW_HALF_MIRROR, 0xf, 0xf, false); v = v > t ? v : t;
-    t = __builtin_amdgcn_update_dpp(v, v, DPP_ROW_MIRROR, 0xf, 0xf, false); v = v > t ? v : t;
-    return v;
-}
-static __device__ inline int row_all_sum(int v)
-{
-    v += __builtin_amdgcn_update_dpp(v, v, DPP_QUAD_PERM(1, 0, 3, 2), 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(v, v, DPP_QUAD_PERM(2, 3, 0, 1), 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(v, v, DPP_ROW_HALF_MIRROR, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(v, v, DPP_ROW_MIRROR, 0xf, 0xf, false);
-    return v;
-}
-// order the row's memory accesses around a hand-over between its lanes (a wave executes in lockstep: no barrier instruction needed)
-static __device__ inline void row_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }

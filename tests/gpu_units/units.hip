@@ -24,17 +24,8 @@ __global__ void __launch_bounds__(64) k_unit_extend(DevIndex ix, MemOpt opt, con
     for (int j = lane; j < qlen; j += WAVE) sq[j] = query[j];
     __syncthreads();
     unsigned long long n_cells = 0;
-    ExtRes r;
-    int ok = 1;
-    if (force_lds == 3) {                                       // the group form's band-limited DP: every 16-lane row runs the same job
-        __shared__ uint8_t tbuf[4][288];
-        GrpLds G; G.query = sq; G.target = tbuf[lane >> 4];
-        ok = extend_band(ix, opt, G, lane & 15, qlen, 0, 1, tlen, 0, 1, w, end_bonus, zdrop, h0, n_cells, r) ? 1 : 0;
-        if (!ok) { r.score = r.qle = r.tle = r.gtle = r.gscore = r.max_off = 0; }
-    } else
-        r = force_lds == 1 ? extend_wave(ix, opt, L, lane, qlen, 0, 1, tlen, 0, 1, w, end_bonus, zdrop, h0, n_cells)
-                           : extend_any(ix, opt, L, lane, qlen, 0, 1, tlen, 0, 1, w, end_bonus, zdrop, h0, n_cells, force_lds == 2);   // 2: with the diagonal certificate
-    if (lane == 0) out[6] = ok;
+    ExtRes r = force_lds == 1 ? extend_wave(ix, opt, L, lane, qlen, 0, 1, tlen, 0, 1, w, end_bonus, zdrop, h0, n_cells)
+                         : extend_any(ix, opt, L, lane, qlen, 0, 1, tlen, 0, 1, w, end_bonus, zdrop, h0, n_cells, force_lds == 2);   // 2: with the diagonal certificate
     if (lane == 0) { out[0] = r.score; out[1] = r.qle; out[2] = r.tle; out[3] = r.gtle; out[4] = r.gscore; out[5] = r.max_off; }
 }
 
@@ -71,7 +62,7 @@ extern "C" int unit_extend(const uint8_t* query, int qlen, const uint8_t* target
     size_t cap = (size_t)qlen + 2, shmem = 3 * cap * 4 + ((cap + 15) & ~(size_t)15);
     hipLaunchKernelGGL(k_unit_extend, dim3(1), dim3(64), shmem, 0, ix, *opt, d_q, qlen, tlen, w, end_bonus, zdrop, h0, d_out, force_lds);
     int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -1;
-    hipMemcpy(out6, d_out, 28, hipMemcpyDeviceToHost);
+    hipMemcpy(out6, d_out, 24, hipMemcpyDeviceToHost);
     hipFree(d_pac); hipFree(d_q); hipFree(d_out);
     return rc;
 }
