@@ -15,7 +15,10 @@
 
 struct ExtRes { int score, qle, tle, gtle, gscore, max_off; };
 
-struct ExtLds { int32_t* eh_h; int32_t* eh_e; int32_t* tmpM; const uint8_t* query; };
+// rm: index mask of the rows.  Only the band around the current row is ever live (columns i - w .. i + w + 1), so the rows of
+// the general form are rings of a power-of-two size >= 2 w + 4 instead of arrays as long as the read: a 10 kb read needs 6 KB
+// of LDS for its rows, not 120 KB, and a CU holds ten such wavefronts instead of one.  (Rows in global memory: rm = ~0.)
+struct ExtLds { int32_t* eh_h; int32_t* eh_e; int32_t* tmpM; const uint8_t* query; int rm; };
 
 // Early exit of the extension DP (both forms below).  Upstream's ksw_extend2 keeps computing rows until the target
 // runs out, the row maximum is 0 or the z-drop test fires; for a query that has been matched to its end that means
@@ -43,16 +46,7 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
     int i, beg, end, max, max_i, max_j, max_ins, max_del, max_ie, gscore, max_off;
     if (h0 < 0) h0 = 0;
     const ScoreTab ST = score_tab(opt);
-    // first row: decay from h0 by insertion costs
-    for (int j = lane; j <= qlen; j += WAVE) {
-        int v = 0;
-        if (j == 0) v = h0;
-        else if (h0 > oe_ins) {
-            int vj = h0 - oe_ins - (j - 1) * e_ins;       // value if the decay chain reaches column j
-            if (j == 1 || vj + e_ins > e_ins) v = vj;     // previous cell > e_ins
-        }
-        L.eh_h[j] = v; L.eh_e[j] = 0;
-    }
+    const int RM = L.rm;
     const int mx = score_max(opt);
     {   // clip the band by the longest affordable gap
         max_ins = div_plus(qlen * mx + end_bonus - o_ins, e_ins, 1);
@@ -62,6 +56,10 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
         max_del = max_del > 1 ? max_del : 1;
         w = w < max_del ? w : max_del;
     }
+    // first row: decay from h0 by insertion costs.  Index j of the row is H(-1, j-1); the ring holds indices 0 .. w + 1 now and
+    // every row below adds the index the band is about to reach (no earlier row can have written it)
+#define EXT_INIT_H(j) ((j) == 0 ? h0 : h0 > oe_ins && h0 - oe_ins - ((j) - 1) * e_ins > 0 ? h0 - oe_ins - ((j) - 1) * e_ins : 0)
+    for (int j = lane; j <= qlen && j <= w + 1; j += WAVE) { L.eh_h[j & RM] = EXT_INIT_H(j); L.eh_e[j & RM] = 0; }
     max = h0; max_i = max_j = -1; max_ie = -1; gscore = -1; max_off = 0;
     beg = 0; end = qlen;
     int tch = 4;
@@ -71,6 +69,7 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
             int ii = i + lane;
             tch = ii < tlen ? ref_base2(ix, t0 + (int64_t)tstep * ii) : 4;
         }
+        if (lane == 0 && i + w + 1 <= qlen) { L.eh_h[(i + w + 1) & RM] = EXT_INIT_H(i + w + 1); L.eh_e[(i + w + 1) & RM] = 0; }
         const int tb = wave_bcast(tch, i & 63);
         const int ms0 = score_at(ST.p[0], ST.n[0], tb), ms1 = score_at(ST.p[1], ST.n[1], tb), ms2 = score_at(ST.p[2], ST.n[2], tb), ms3 = score_at(ST.p[3], ST.n[3], tb), ms4 = score_at(ST.p[4], ST.n[4], tb);
         int m = 0, mj = -1, h1, h1i, hlast = 0;
@@ -84,10 +83,10 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
         for (int c = beg; c < end; c += WAVE) {
             int j = c + lane;
             if (j < end) {
-                int Mp = L.eh_h[j];
+                int Mp = L.eh_h[j & RM];
                 int qc = L.query[q0 + qstep * j];
                 int sc = qc == 0 ? ms0 : qc == 1 ? ms1 : qc == 2 ? ms2 : qc == 3 ? ms3 : ms4;
-                L.tmpM[j] = Mp ? Mp + sc : 0;
+                L.tmpM[j & RM] = Mp ? Mp + sc : 0;
             }
         }
         __syncthreads();
@@ -96,8 +95,8 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
         for (int c = beg; c < end; c += WAVE) {
             int j = c + lane;
             bool act = j < end;
-            int M = act ? L.tmpM[j] : 0;
-            int e = act ? L.eh_e[j] : 0;
+            int M = act ? L.tmpM[j & RM] : 0;
+            int e = act ? L.eh_e[j & RM] : 0;
             int t = M - oe_ins; t = t > 0 ? t : 0;
             int U = act ? t + j * e_ins : NEG_INF_I32;
             int P = wave_prefix_max(U, lane);
@@ -121,16 +120,16 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
             if (act) {
                 int t2 = M - oe_del; t2 = t2 > 0 ? t2 : 0;
                 int en = e - e_del; en = en > t2 ? en : t2;
-                L.eh_e[j] = en;
-                L.eh_h[j + 1] = h;
+                L.eh_e[j & RM] = en;
+                L.eh_h[(j + 1) & RM] = h;
             }
         }
         if (end > beg) {                                   // eh[beg].h = first-column value, eh[end].h = H(i,end-1)
             n_cells += (unsigned long long)(end - beg);
             h1 = hlast;
-            if (lane == 0) L.eh_h[beg] = h1i;
-        } else if (lane == 0) L.eh_h[end] = h1i;
-        if (lane == 0) L.eh_e[end] = 0;
+            if (lane == 0) L.eh_h[beg & RM] = h1i;
+        } else if (lane == 0) L.eh_h[end & RM] = h1i;
+        if (lane == 0) L.eh_e[end & RM] = 0;
         {
             int jafter = end > beg ? end : beg;
             if (jafter == qlen) {
@@ -156,7 +155,7 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
             int nb = end;
             for (int c = beg; c < end; c += WAVE) {
                 int j = c + lane;
-                int nz = j < end && (L.eh_h[j] != 0 || L.eh_e[j] != 0);
+                int nz = j < end && (L.eh_h[j & RM] != 0 || L.eh_e[j & RM] != 0);
                 unsigned long long bal = wave_ballot(nz);
                 if (bal) { nb = c + __ffsll((long long)bal) - 1; break; }
             }
@@ -164,7 +163,7 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
             int jl = beg - 1;
             for (int hi = end; hi >= beg; hi -= WAVE) {
                 int p = hi - lane;
-                int nz = p >= beg && (L.eh_h[p] != 0 || L.eh_e[p] != 0);
+                int nz = p >= beg && (L.eh_h[p & RM] != 0 || L.eh_e[p & RM] != 0);
                 unsigned long long bal = wave_ballot(nz);
                 if (bal) { jl = hi - (__ffsll((long long)bal) - 1); break; }
             }
@@ -173,12 +172,17 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
         __syncthreads();
         if (gscore > 0 && m + mx * (qlen - 1 - mj) <= max) {   // see ext_bound(): the remaining rows cannot change the result
             int B = 0;
-            for (int c = beg; c < qlen; c += WAVE) {
+            const int lim = qlen < i + w + 3 ? qlen : i + w + 3;        // indices the ring holds (the next row's entering index included)
+            if (lane == 0 && i + w + 2 <= qlen) { L.eh_h[(i + w + 2) & RM] = EXT_INIT_H(i + w + 2); L.eh_e[(i + w + 2) & RM] = 0; }
+            __syncthreads();
+            for (int c = beg; c < lim; c += WAVE) {
                 const int j = c + lane;
-                const int term = j < qlen ? ext_bound_term(L.eh_h[j], L.eh_e[j], mx, qlen - 1 - j) : 0;
+                const int term = j < lim ? ext_bound_term(L.eh_h[j & RM], L.eh_e[j & RM], mx, qlen - 1 - j) : 0;
                 const int bc = wave_max(term);
                 B = B > bc ? B : bc;
             }
+            // indices beyond hold the untouched first row, whose terms fall with j: the first of them is the largest
+            if (lim < qlen) { const int t0 = ext_bound_term(EXT_INIT_H(lim), 0, mx, qlen - 1 - lim); B = B > t0 ? B : t0; }
             if (beg == 0) { const int hb = h0 - (o_del + e_del * (i + 2)); if (hb > 0 && hb + mx * qlen > B) B = hb + mx * qlen; }
             if (B <= max && B < gscore) break;
         }
@@ -407,6 +411,17 @@ static __device__ ExtRes extend_any(const DevIndex& ix, const MemOpt& opt, const
 
 struct U64Lt { __device__ bool operator()(uint64_t a, uint64_t b) const { return a < b; } };
 
+// entries of the row rings of the general form: a power of two >= 2 w + 4 for the widest band tried (opt.w << (MAX_BAND_TRY - 1)),
+// never more than the read needs
+static __host__ __device__ inline int extend_ring(const MemOpt& opt, int max_len)
+{
+    long long need = 4ll * (opt.w > 0 ? opt.w : 0) + 8;
+    if (need > (long long)max_len + 4) need = (long long)max_len + 4;
+    int r = 64;
+    while (r < need) r <<= 1;
+    return r;
+}
+
 #define MAX_BAND_TRY 2
 
 // minimum resident waves per SIMD the register allocator must leave room for (the DP rows are one long dependent
@@ -427,12 +442,13 @@ static __device__ __forceinline__ void extend_read(const DevIndex& ix, const Mem
     uint8_t* sq;
     if (HBM) {
         int32_t* rows = tv.dp_rows + (size_t)blockIdx.x * 3 * (size_t)cap;
-        L.eh_h = rows; L.eh_e = rows + cap; L.tmpM = rows + 2 * cap;
+        L.eh_h = rows; L.eh_e = rows + cap; L.tmpM = rows + 2 * cap; L.rm = 0x7fffffff;
         sq = (uint8_t*)smem;
     } else {                                                    // the read first: tiles of short reads (register form only) allocate nothing else
         sq = (uint8_t*)smem;
         int32_t* rows = smem + (((size_t)cap + 15) & ~(size_t)15) / 4;
-        L.eh_h = rows; L.eh_e = rows + cap; L.tmpM = rows + 2 * cap;
+        const int ring = extend_ring(opt, tv.max_len);
+        L.eh_h = rows; L.eh_e = rows + ring; L.tmpM = rows + 2 * ring; L.rm = ring - 1;
     }
     L.query = sq;
     for (int j = lane; j < l_query; j += WAVE) sq[j] = tv.seq[tv.seq_off[r] + j];
@@ -588,10 +604,10 @@ __global__ void __launch_bounds__(64, K_EXTEND_MIN_WAVES) k_extend(DevIndex ix, 
 }
 
 // LDS of one k_extend workgroup for reads of up to max_len bases: the H, E and M rows of the general form + the read
-size_t extend_lds_bytes(int max_len)
+size_t extend_lds_bytes(const MemOpt& opt, int max_len)
 {
     size_t cap = (size_t)max_len + 2;
-    return 3 * cap * sizeof(int32_t) + ((cap + 15) & ~(size_t)15);
+    return 3 * (size_t)extend_ring(opt, max_len) * sizeof(int32_t) + ((cap + 15) & ~(size_t)15);
 }
 void launch_extend(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv)
 {
@@ -604,6 +620,6 @@ void launch_extend(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const 
     }
     // every query of a tile whose reads are at most 3 * 64 - 1 bases long takes the register form: no rows in LDS, only the
     // read -- which matters for overlap, because k_seed fills the CUs' LDS and a workgroup that asks for 2 KB finds no room
-    size_t shmem = tv.max_len + 1 <= 3 * WAVE ? (((size_t)tv.max_len + 2 + 15) & ~(size_t)15) : extend_lds_bytes(tv.max_len);
+    size_t shmem = tv.max_len + 1 <= 3 * WAVE ? (((size_t)tv.max_len + 2 + 15) & ~(size_t)15) : extend_lds_bytes(opt, tv.max_len);
     hipLaunchKernelGGL(k_extend<false>, dim3(tv.n_reads), dim3(64), shmem, st, ix, opt, tv);
 }

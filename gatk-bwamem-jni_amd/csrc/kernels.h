@@ -18,7 +18,7 @@ void launch_chain(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const T
 // seed re-scoring (long reads): jobs/results sized by pe_rescue_bytes for `cap` >= the tile's seed count; first_num = 2 x n_reads ints, cnt = 1 int
 bool rescore_needed(const MemOpt& opt, const TileView& tv);
 void launch_rescore(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, void* jobs, void* results, int32_t* first_num, int32_t* cnt, int cap);
-size_t extend_lds_bytes(int max_len);       // dynamic LDS k_extend asks for; the caller checks it against the device limit
+size_t extend_lds_bytes(const MemOpt& opt, int max_len);       // dynamic LDS k_extend asks for; the caller checks it against the device limit
 void launch_extend(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 void launch_post1(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 void launch_final_prep(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);

@@ -72,7 +72,8 @@ static bool dp_rows_in_hbm(int lds, int L)
     if (lds <= 0) lds = 64 << 10;
     const char* e = getenv("BWAMEM_HIP_DP_ROWS");
     if (e && !strcmp(e, "hbm")) return true;
-    return extend_lds_bytes(L) + 6144 + 64 > (size_t)lds;
+    const size_t cap = (size_t)L + 2;                            // k_gcigar's wave form: three rows as long as the read, the read, its traceback window
+    return 3 * cap * sizeof(int32_t) + ((cap + 15) & ~(size_t)15) + 6144 + 64 > (size_t)lds;
 }
 
 struct Workspace {

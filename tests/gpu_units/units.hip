@@ -18,8 +18,10 @@ __global__ void __launch_bounds__(64) k_unit_extend(DevIndex ix, MemOpt opt, con
     HIP_DYNAMIC_SHARED(int32_t, smem)
     const int cap = qlen + 2, lane = threadIdx.x;
     ExtLds L;
-    L.eh_h = smem; L.eh_e = smem + cap; L.tmpM = smem + 2 * cap;
-    uint8_t* sq = (uint8_t*)(smem + 3 * cap);
+    const int ring = extend_ring(opt, qlen);                    // the row rings, sized as production sizes them
+    L.eh_h = smem; L.eh_e = smem + ring; L.tmpM = smem + 2 * ring; L.rm = ring - 1;
+    uint8_t* sq = (uint8_t*)(smem + 3 * ring);
+    (void)cap;
     L.query = sq;
     for (int j = lane; j < qlen; j += WAVE) sq[j] = query[j];
     __syncthreads();
@@ -59,7 +61,7 @@ extern "C" int unit_extend(const uint8_t* query, int qlen, const uint8_t* target
     hipMemcpy(d_q, query, (size_t)qlen, hipMemcpyHostToDevice);
     DevIndex ix; memset(&ix, 0, sizeof ix);
     ix.pac = d_pac; ix.l_pac = tlen;
-    size_t cap = (size_t)qlen + 2, shmem = 3 * cap * 4 + ((cap + 15) & ~(size_t)15);
+    size_t cap = (size_t)qlen + 2, shmem = 3 * (size_t)extend_ring(*opt, qlen) * 4 + ((cap + 15) & ~(size_t)15);
     hipLaunchKernelGGL(k_unit_extend, dim3(1), dim3(64), shmem, 0, ix, *opt, d_q, qlen, tlen, w, end_bonus, zdrop, h0, d_out, force_lds);
     int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -1;
     hipMemcpy(out6, d_out, 24, hipMemcpyDeviceToHost);
