@@ -15,48 +15,79 @@
 
 #define NEG_SCAN (-2000000000)
 
-struct GLds { int32_t* eh_h; int32_t* eh_e; int32_t* tmpM; };
+struct GLds { int32_t* eh_h; int32_t* eh_e; int32_t* tmpM; int rm; };   // rm: ring mask of the rows (only columns i - w .. i + w + 1 are live: see ExtLds in k_extend.hip); ~0 for rows in global memory
 
 // backtrack through the direction bytes (lane 0); ops come out end-to-start and are reversed in place.  The run being
 // built stays in registers: the CIGAR pool is global memory, and a read-modify-write per step would put a global
 // round trip on every one of the ~tlen steps.
-static __device__ int traceback(const uint8_t* z, int n_col, int w, int tlen, int qlen, int lane, uint32_t* cigar, int cig_cap, int& err)
+static __device__ int traceback(const uint8_t* z, int n_col, int w, int tlen, int qlen, int lane, uint32_t* cigar, int cig_cap, int& err, uint8_t* tile)
 {
     int n = 0;
-    if (lane == 0) {
-        int which = 0, i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
-        int cur_op = -1;
-        uint32_t cur_len = 0;
-        bool ovf = false;
+    int which = 0, i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+    int cur_op = -1;
+    uint32_t cur_len = 0;
+    bool ovf = false;
 #define TB_PUSH(OP, LEN) do { if ((OP) == cur_op) cur_len += (uint32_t)(LEN); else { \
-            if (cur_len) { if (n >= cig_cap) ovf = true; else cigar[n++] = cur_len << 4 | (uint32_t)cur_op; } cur_op = (OP); cur_len = (uint32_t)(LEN); } } while (0)
-        while (i >= 0 && k >= 0 && !ovf) {
-            which = z[i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
-            if (which == 0) { TB_PUSH(0, 1); --i; --k; }
-            else if (which == 1) { TB_PUSH(2, 1); --i; }
-            else { TB_PUSH(1, 1); --k; }
+        if (cur_len) { if (n >= cig_cap) ovf = true; else cigar[n++] = cur_len << 4 | (uint32_t)cur_op; } cur_op = (OP); cur_len = (uint32_t)(LEN); } } while (0)
+    if (!tile) {                                                  // the matrix is in LDS: lane 0 walks it directly
+        if (lane == 0)
+            while (i >= 0 && k >= 0 && !ovf) {
+                which = z[i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+                if (which == 0) { TB_PUSH(0, 1); --i; --k; }
+                else if (which == 1) { TB_PUSH(2, 1); --i; }
+                else { TB_PUSH(1, 1); --k; }
+            }
+    } else {
+        // The matrix is in global memory (long reads: megabytes per job), and a walk of one dependent global load per step
+        // costs a microsecond a step.  The path moves up and/or left by one cell per step, so the 64 x 64 cells up-left of
+        // the current one hold its next 64 steps at least: the wave stages that tile in LDS (64 coalesced byte loads in
+        // flight), lane 0 walks inside it, and so on.
+        for (;;) {
+            const int i0 = wave_bcast(i, 0), k0 = wave_bcast(k, 0);
+            if (i0 < 0 || k0 < 0 || wave_bcast(ovf ? 1 : 0, 0)) break;
+            __syncthreads();
+            for (int t = 0; t < 64; ++t) {
+                const int r = i0 - t, c = k0 - 63 + lane;
+                uint8_t bt = 0;
+                if (r >= 0 && c >= 0) {
+                    const int rb = r > w ? r - w : 0, re = r + w + 1 < qlen ? r + w + 1 : qlen;
+                    if (c >= rb && c < re) bt = z[(int64_t)r * n_col + (c - rb)];
+                }
+                tile[t * 64 + lane] = bt;
+            }
+            __syncthreads();
+            if (lane == 0)
+                while (i >= 0 && k >= 0 && !ovf && i > i0 - 64 && k > k0 - 64) {
+                    which = tile[(i0 - i) * 64 + (k - (k0 - 63))] >> (which << 1) & 3;
+                    if (which == 0) { TB_PUSH(0, 1); --i; --k; }
+                    else if (which == 1) { TB_PUSH(2, 1); --i; }
+                    else { TB_PUSH(1, 1); --k; }
+                }
         }
+    }
+    if (lane == 0) {
         if (!ovf && i >= 0) TB_PUSH(2, i + 1);
         if (!ovf && k >= 0) TB_PUSH(1, k + 1);
         if (!ovf) TB_PUSH(-1, 0);                                 // flush the last run
-#undef TB_PUSH
         for (int a = 0; a < n >> 1; ++a) { uint32_t tmp = cigar[a]; cigar[a] = cigar[n - 1 - a]; cigar[n - 1 - a] = tmp; }
         if (ovf) { err |= ERR_CIGAR_CAP; n = 0; }
     }
+#undef TB_PUSH
     return wave_bcast(n, 0);
 }
 
 // one ksw_global2 call; the raw CIGAR (before clip / deletion squeezing) goes to cigar[0..*n_cigar)
 static __device__ int global_wave(const DevIndex& ix, const MemOpt& opt, const GLds& L, int lane, const SeqAcc& A, int w,
-                                  uint8_t* z, int n_col, uint32_t* cigar, int cig_cap, int* n_cigar, int& err)
+                                  uint8_t* z, int n_col, uint32_t* cigar, int cig_cap, int* n_cigar, int& err, uint8_t* tile)
 {
+    const int RM = L.rm;
     const int qlen = A.qlen, tlen = A.tlen;
     const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const ScoreTab ST = score_tab(opt);
-    for (int j = lane; j <= qlen; j += WAVE) {
-        L.eh_h[j] = j == 0 ? 0 : (j <= w ? -(o_ins + e_ins * j) : MINUS_INF);
-        L.eh_e[j] = MINUS_INF;
+    for (int j = lane; j <= qlen && j <= w + 1; j += WAVE) {     // (row i writes index i + w + 1 itself before row i + 1 reads it)
+        L.eh_h[j & RM] = j == 0 ? 0 : (j <= w ? -(o_ins + e_ins * j) : MINUS_INF);
+        L.eh_e[j & RM] = MINUS_INF;
     }
     int tch = 4;
     __syncthreads();
@@ -72,7 +103,7 @@ static __device__ int global_wave(const DevIndex& ix, const MemOpt& opt, const G
             if (j < end) {
                 int qc = acc_q(A, j);
                 int sc = qc == 0 ? ms0 : qc == 1 ? ms1 : qc == 2 ? ms2 : qc == 3 ? ms3 : ms4;
-                L.tmpM[j] = L.eh_h[j] + sc;
+                L.tmpM[j & RM] = L.eh_h[j & RM] + sc;
             }
         }
         __syncthreads();
@@ -81,8 +112,8 @@ static __device__ int global_wave(const DevIndex& ix, const MemOpt& opt, const G
         for (int c = beg; c < end; c += WAVE) {                     // phase B: F by scan, H, E, direction bits
             int j = c + lane;
             bool act = j < end;
-            int m = act ? L.tmpM[j] : 0;
-            int e = act ? L.eh_e[j] : 0;
+            int m = act ? L.tmpM[j & RM] : 0;
+            int e = act ? L.eh_e[j & RM] : 0;
             int tins = m - oe_ins;
             int U = act ? tins + j * e_ins : NEG_SCAN;
             int P = wave_prefix_max(U, lane);
@@ -102,18 +133,18 @@ static __device__ int global_wave(const DevIndex& ix, const MemOpt& opt, const G
             hlast = wave_bcast(h, last);
             int Plast = wave_bcast(P, 63);
             { int f1 = fcarry - WAVE * e_ins, f2 = Plast - (c + 63) * e_ins; fcarry = f1 > f2 ? f1 : f2; }
-            if (act) { zi[j - beg] = (uint8_t)d; L.eh_e[j] = e2; L.eh_h[j + 1] = h; }
+            if (act) { zi[j - beg] = (uint8_t)d; L.eh_e[j & RM] = e2; L.eh_h[(j + 1) & RM] = h; }
         }
         if (lane == 0) {
-            if (end > beg) L.eh_h[beg] = h1i;
-            else L.eh_h[end] = h1i;
-            L.eh_e[end] = MINUS_INF;
+            if (end > beg) L.eh_h[beg & RM] = h1i;
+            else L.eh_h[end & RM] = h1i;
+            L.eh_e[end & RM] = MINUS_INF;
         }
         (void)hlast;
         __syncthreads();
     }
-    const int score = L.eh_h[qlen];
-    *n_cigar = traceback(z, n_col, w, tlen, qlen, lane, cigar, cig_cap, err);
+    const int score = L.eh_h[qlen & RM];
+    *n_cigar = traceback(z, n_col, w, tlen, qlen, lane, cigar, cig_cap, err, tile);
     __syncthreads();
     return score;
 }
@@ -124,7 +155,7 @@ static __device__ int global_wave(const DevIndex& ix, const MemOpt& opt, const G
 // and the query slides down the lanes one position per row.  Nothing of the DP state lives in LDS and no barrier is
 // needed; only the direction bytes are stored (z, in upstream's [row][column - beg] layout) for the traceback.
 static __device__ int global_wave_diag(const DevIndex& ix, const MemOpt& opt, const uint8_t* sq, int lane, const SeqAcc& A, int w,
-                                       uint8_t* z, int n_col, uint32_t* cigar, int cig_cap, int* n_cigar, int& err)
+                                       uint8_t* z, int n_col, uint32_t* cigar, int cig_cap, int* n_cigar, int& err, uint8_t* tile)
 {
     const int qlen = A.qlen, tlen = A.tlen;
     const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
@@ -170,7 +201,7 @@ static __device__ int global_wave_diag(const DevIndex& ix, const MemOpt& opt, co
         qv = dpp_shl1(qv, qin);
     }
     const int score = wave_bcast(h, qlen - 1 - (tlen - 1 - w));     // H(tlen-1, qlen-1); the caller checked that lane is in the band
-    *n_cigar = traceback(z, n_col, w, tlen, qlen, lane, cigar, cig_cap, err);
+    *n_cigar = traceback(z, n_col, w, tlen, qlen, lane, cigar, cig_cap, err, tile);
     return score;
 }
 
@@ -320,9 +351,11 @@ __global__ void __launch_bounds__(64, 2) k_gcigar_lane(DevIndex ix, MemOpt opt, 
 }
 
 // HBM: as in k_extend -- rows of the general form in a slice of tv.dp_rows instead of LDS, a bounded grid walking the jobs
+// HBM = false: rows as rings of `ring` entries in LDS; a job whose band needs more than that is left for the HBM kernel
+// (launched after this one whenever the tile's reads are longer than the ring).
 template <bool HBM>
 __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView tv, const DpJob* jobs, DpOut* outs, int n_jobs, uint32_t* cig_pool, int cig_cap,
-                                               uint8_t* zpool, unsigned long long zpool_cap, unsigned long long* zpool_cur, int z_lds_cap)
+                                               uint8_t* zpool, unsigned long long zpool_cap, unsigned long long* zpool_cur, int z_lds_cap, int ring)
 {
     HIP_DYNAMIC_SHARED(int32_t, smem)
     const int lane = threadIdx.x;
@@ -337,11 +370,11 @@ __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView
     uint8_t* sq;                                                       // the region's query bases, in alignment order
     if (HBM) {
         int32_t* rows = tv.dp_rows + (size_t)blockIdx.x * 3 * (size_t)cap;
-        L.eh_h = rows; L.eh_e = rows + cap; L.tmpM = rows + 2 * cap;
+        L.eh_h = rows; L.eh_e = rows + cap; L.tmpM = rows + 2 * cap; L.rm = 0x7fffffff;
         sq = (uint8_t*)smem;
     } else {
-        L.eh_h = smem; L.eh_e = smem + cap; L.tmpM = smem + 2 * cap;
-        sq = (uint8_t*)(smem + 3 * cap);
+        L.eh_h = smem; L.eh_e = smem + ring; L.tmpM = smem + 2 * ring; L.rm = ring - 1;
+        sq = (uint8_t*)(smem + 3 * ring);
     }
     uint8_t* z_lds = sq + ((cap + 15) & ~15);
     int err = 0;
@@ -351,6 +384,7 @@ __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView
     int w2 = first_w2(opt, ar), i = 0, last_sc = -(1 << 30), score = 0, n_cigar = 0;
     const int l_query = A.qlen, rlen = A.tlen;
     const bool usable = !(l_query <= 0 || ar.rb >= ar.re || (ar.rb < ix.l_pac && ar.re > ix.l_pac) || ar.re > ix.l_pac << 1 || ar.rb < 0);
+    bool deferred = false;                                             // band too wide for the LDS rings: the HBM kernel takes the job
     if (usable) {
         for (int j = lane; j < l_query; j += WAVE) sq[j] = (uint8_t)acc_q(A, j);
         __syncthreads();
@@ -366,6 +400,7 @@ __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView
             w = w < w2 ? w : w2;
             min_w = d + 3;
             w = w > min_w ? w : min_w;
+            if (!HBM && 2 * w + 4 > ring && l_query + 2 > ring) { deferred = true; break; }
             const int n_col = l_query < 2 * w + 1 ? l_query : 2 * w + 1;
             const unsigned long long need = (unsigned long long)n_col * (unsigned long long)rlen;
             uint8_t* z = z_lds;
@@ -377,14 +412,15 @@ __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView
                 z = zpool + at;
             }
             const int l_end = l_query - 1 - (rlen - 1 - w);            // lane of the final cell in the diagonal form
-            if (2 * w + 1 <= WAVE && l_end >= 0 && l_end <= 2 * w) score = global_wave_diag(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err);
-            else score = global_wave(ix, opt, L, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err);
+            uint8_t* tile = z == z_lds || z_lds_cap < 4096 ? nullptr : z_lds;   // a matrix in global memory is walked through 64 x 64 tiles staged where the small ones live
+            if (2 * w + 1 <= WAVE && l_end >= 0 && l_end <= 2 * w) score = global_wave_diag(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
+            else score = global_wave(ix, opt, L, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
             if (score == last_sc || w2 == opt.w << 2) break;
             last_sc = score;
             w2 <<= 1;
         } while (++i < 3 && score < ar.truesc - opt.a);
     }
-    if (lane == 0) {
+    if (lane == 0 && !deferred) {
         DpOut o; o.score = score; o.n_cigar = n_cigar;
         outs[job] = o;
         if (err) atomicOr(tv.err, err);
@@ -399,12 +435,16 @@ void launch_gcigar(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const 
     int z_lds_cap = 6144;                                            // covers bands of ~40 columns x 150 rows; larger matrices go to the HBM pool
     { const char* e = getenv("BWAMEM_HIP_ZLDS"); if (e && atoi(e) >= 0) z_lds_cap = atoi(e); }
     size_t cap = (size_t)tv.max_len + 2;
-    size_t shmem = 3 * cap * sizeof(int32_t) + ((cap + 15) & ~(size_t)15) + (size_t)z_lds_cap + 64;
+    // rows of the wave form: rings that hold the widest band mem_reg2aln asks for (opt.w << 2) -- or the whole read when that
+    // is shorter.  Jobs whose band is wider still (regions with a long net indel) go to the HBM kernel behind it.
+    int ring = 64;
+    { long long need = 8ll * (opt.w > 0 ? opt.w : 0) + 8; if (need > (long long)cap + 2) need = (long long)cap + 2; if (need > 16384) need = 16384; while (ring < need) ring <<= 1; }
+    const size_t tail = ((cap + 15) & ~(size_t)15) + (size_t)z_lds_cap + 64;
     hipLaunchKernelGGL(k_gcigar_lane<16>, dim3((n_jobs + 63) / 64), dim3(64), 0, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur);
+    if (!tv.gcigar_hbm_only)
+        hipLaunchKernelGGL(k_gcigar<false>, dim3(n_jobs), dim3(64), 3 * (size_t)ring * sizeof(int32_t) + tail, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap, ring);
     if (tv.dp_rows) {
         const int grid = n_jobs < tv.dp_rows_blocks ? n_jobs : tv.dp_rows_blocks;
-        hipLaunchKernelGGL(k_gcigar<true>, dim3(grid), dim3(64), ((cap + 15) & ~(size_t)15) + (size_t)z_lds_cap + 64, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap);
-        return;
+        hipLaunchKernelGGL(k_gcigar<true>, dim3(grid), dim3(64), tail, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap, 0);
     }
-    hipLaunchKernelGGL(k_gcigar<false>, dim3(n_jobs), dim3(64), shmem, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap);
 }

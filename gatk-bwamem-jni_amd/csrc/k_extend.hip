@@ -612,7 +612,7 @@ size_t extend_lds_bytes(const MemOpt& opt, int max_len)
 void launch_extend(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv)
 {
     if (tv.n_reads <= 0) return;
-    if (tv.dp_rows) {                                           // rows in global memory: tv.dp_rows_blocks slices of 3 x (max_len + 2) ints
+    if (tv.ext_hbm && tv.dp_rows) {                             // rows in global memory: tv.dp_rows_blocks slices of 3 x (max_len + 2) ints
         const size_t cap = (size_t)tv.max_len + 2;
         const int grid = tv.n_reads < tv.dp_rows_blocks ? tv.n_reads : tv.dp_rows_blocks;
         hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(64), (cap + 15) & ~(size_t)15, st, ix, opt, tv);

@@ -64,16 +64,18 @@ enum KernelId { K_ENCODE, K_SEED, K_SA, K_CHAIN, K_EXTEND, K_POST, K_FINAL, K_PA
 
 struct Timed { KernelId id; hipEvent_t a, b; };
 
-// Do the DP rows of the general extension / global-alignment forms fit a CU's LDS for reads of L bases (13 bytes per base:
-// up to about 12 000 bases with 160 KB)?  If not they live in global memory (k_extend<true>, k_gcigar<true>).
-// BWAMEM_HIP_DP_ROWS=hbm forces that path (tests).
-static bool dp_rows_in_hbm(int lds, int L)
+// DP rows in global memory (tv.dp_rows).  The wave forms of k_extend and k_gcigar keep their rows in LDS as rings around
+// the band, so this is the exception: k_gcigar jobs whose band is wider than its rings (regions with a long net indel,
+// only possible when the reads are longer than the rings), k_extend for reads that do not fit LDS next to the rings, and
+// BWAMEM_HIP_DP_ROWS=hbm, which sends everything there (tests).
+static void dp_rows_policy(int lds, const MemOpt& opt, int L, bool& need_rows, bool& ext_hbm, bool& gcigar_hbm_only)
 {
     if (lds <= 0) lds = 64 << 10;
     const char* e = getenv("BWAMEM_HIP_DP_ROWS");
-    if (e && !strcmp(e, "hbm")) return true;
-    const size_t cap = (size_t)L + 2;                            // k_gcigar's wave form: three rows as long as the read, the read, its traceback window
-    return 3 * cap * sizeof(int32_t) + ((cap + 15) & ~(size_t)15) + 6144 + 64 > (size_t)lds;
+    const bool forced = e && !strcmp(e, "hbm");
+    ext_hbm = forced || extend_lds_bytes(opt, L) + 64 > (size_t)lds;
+    gcigar_hbm_only = forced || (size_t)L + 4 + 3 * 1024 * 4 + 6144 + 64 > (size_t)lds;    // (the read itself next to the smallest useful rings)
+    need_rows = forced || ext_hbm || gcigar_hbm_only || (long long)L + 4 > 8ll * (opt.w > 0 ? opt.w : 0) + 8;
 }
 
 struct Workspace {
@@ -82,7 +84,8 @@ struct Workspace {
     DevBuf intv, n_intv, smem, l_rep, n_seeds, seed_off, intv_seed_off;
     DevBuf seeds, seed_rid, cseeds, chains, chain_store, n_chains, bt_nodes, srt, regs, n_regs;
     DevBuf out, out_len, out_off, post, err, cnt;
-    DevBuf dp_rows; int dp_rows_blocks = 0;          // DP rows of k_extend / k_gcigar in global memory, only for reads too long for LDS rows
+    DevBuf dp_rows; int dp_rows_blocks = 0;          // DP rows of k_extend / k_gcigar in global memory (dp_rows_policy)
+    bool ext_hbm = false, gcigar_hbm_only = false;
     DevBuf jobs, job_out, job_cig, job_cnt, zpool;   // single-end global-alignment jobs
     int job_cap = 0, job_cig_cap = 0; size_t zpool_cap = 0;
     int out_cap_hint = 512;                           // bytes per read of the output staging slots (grown on overflow, kept across tiles)
@@ -93,13 +96,15 @@ struct Workspace {
     std::vector<Timed> timed;
 
     // with_seed = false: the tile takes its interval lists from a SeedStore (single-end path) and needs no seeding arrays
-    bool ensure_reads(int T_, int L_, int intv_cap_, int out_cap_, int64_t post_per_read_, bool with_seed = true) {
+    bool ensure_reads(const MemOpt& opt, int T_, int L_, int intv_cap_, int out_cap_, int64_t post_per_read_, bool with_seed = true) {
         T = T_; L = L_; intv_cap = intv_cap_; smem_cap = L_ + 2; out_cap = out_cap_; post_per_read = post_per_read_;
         size_t t = (size_t)T;
         if (with_seed && !(intv.ensure(t * intv_cap * sizeof(Intv)) && n_intv.ensure(t * 4) && smem.ensure(((t + 63) / 64 * 64) * 2 * smem_cap * 16)
             && l_rep.ensure(t * 4) && n_seeds.ensure(t * 4) && intv_seed_off.ensure(t * intv_cap * 4))) return false;
-        dp_rows_blocks = 0;
-        if (!with_seed && dp_rows_in_hbm(dev_lds, L)) {                                  // a bounded grid of workgroups, each with its own three rows (about 2 GB in all)
+        dp_rows_blocks = 0; ext_hbm = gcigar_hbm_only = false;
+        bool need_rows = false;
+        if (!with_seed) dp_rows_policy(dev_lds, opt, L, need_rows, ext_hbm, gcigar_hbm_only);
+        if (need_rows) {                                                            // a bounded grid of workgroups, each with its own three rows (about 2 GB in all)
             const size_t per_block = 3 * ((size_t)L + 2) * 4;
             dp_rows_blocks = (int)std::min<size_t>(4096, std::max<size_t>(256, ((size_t)2 << 30) / per_block));
             if (!dp_rows.ensure((size_t)dp_rows_blocks * per_block)) return false;
@@ -140,6 +145,7 @@ struct Workspace {
         tv.post_scratch = post.as<uint8_t>(); tv.post_scratch_per_read = post_per_read;
         tv.err = err.as<int32_t>(); tv.cnt = cnt.as<DevCounters>();
         tv.dp_rows = dp_rows_blocks ? dp_rows.as<int32_t>() : nullptr; tv.dp_rows_blocks = dp_rows_blocks;
+        tv.ext_hbm = ext_hbm; tv.gcigar_hbm_only = gcigar_hbm_only;
         tv.job_cnt = job_cnt.as<int32_t>(); tv.jobs = jobs.p; tv.job_cap = job_cap;
         tv.smem_groups = (T + 63) / 64;
         { const char* e = getenv("BWAMEM_HIP_DEBUGK"); tv.debug = e ? atoi(e) : 0; }
@@ -179,6 +185,24 @@ struct ReqBuf {
     void release() { seq.release(); off.release(); tmp.release(); if (h_off) (void)hipHostFree(h_off); h_off = nullptr; h_cap = 0; }
 };
 
+// What the tiles of earlier calls needed, per read, shared by all workspaces of an index: a tile is re-run when one of its
+// buffers turns out too small (deterministic kernels, so a retry is exact), and whichever worker picks up the next tile
+// should not have to learn the same sizes again.
+struct CapHints {
+    std::mutex mu;
+    double jobs_per_read = 0, zpool_per_read = 0;
+    int out_cap = 512;
+    void learn(int T, int n_jobs, size_t zpool_cap, int out_cap_) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (T > 0) { jobs_per_read = std::max(jobs_per_read, 1.25 * n_jobs / T); zpool_per_read = std::max(zpool_per_read, (double)zpool_cap / T); }
+        out_cap = std::max(out_cap, out_cap_);
+    }
+    void get(int T, int& jobs, size_t& zpool, int& out_cap_) {
+        std::lock_guard<std::mutex> lk(mu);
+        jobs = (int)std::min(2.0e9, jobs_per_read * T) + 1; zpool = (size_t)(zpool_per_read * T); out_cap_ = out_cap;
+    }
+};
+
 struct bwaidx_s {
     uint8_t* mem = nullptr; size_t l_mem = 0; bool mmapped = false;
     HostIndex h;
@@ -191,6 +215,7 @@ struct bwaidx_s {
     std::vector<Workspace*> extra_ws;   // further tiles in flight (one stream + host thread each)
     Workspace seed_ws;                  // stream, flags and spill area of the seeding stage (single-end path)
     SeedStore seed_store[2];            // double-buffered: chunk c+1 is seeded while the tiles of chunk c run
+    CapHints hints;
     std::vector<ReqBuf*> req_bufs;      // request stretches of a streamed call (jnibwa_createAlignments)
     hipStream_t up_stream = nullptr;    // their uploads
 };
@@ -707,9 +732,10 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
     const int T = (int)(spec.r1 - spec.r0), L = spec.L;
     int attempts = 0, job_cap_hint = 0;
     size_t zpool_hint = (size_t)64 << 20;
+    { size_t z = 0; int oc = 0; ix->hints.get(T, job_cap_hint, z, oc); zpool_hint = std::max(zpool_hint, z); out_cap = std::max(out_cap, oc); }
     for (;;) {
         if (++attempts > 8) { fprintf(stderr, "[bwamem_hip] tile could not be sized after 8 attempts\n"); return false; }
-        if (!ws.ensure_reads(T, L, seeds_of_chunk.cap, out_cap, post_bytes_per_read(L, opt, false), false)) return false;
+        if (!ws.ensure_reads(opt, T, L, seeds_of_chunk.cap, out_cap, post_bytes_per_read(L, opt, false), false)) return false;
         if (!ws.ensure_seeds(std::max<int64_t>(ws.seed_cap, (int64_t)T * 16))) return false;
         {   // the HBM pool also holds the direction nibbles of k_gcigar_lane: 20 bytes per target row of every job
             const int jc = std::max(job_cap_hint, std::max(1024, T / 4));
@@ -765,6 +791,7 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
             fprintf(stderr, "[bwamem_hip] device error flags %d\n", err); return false;
         }
         if (!emit_tile(ws, b, tile_index, tv, out_total, to)) return false;
+        ix->hints.learn(T, n_jobs, ws.zpool_cap, out_cap);
         {
             std::lock_guard<std::mutex> lk(g_stats.mu);
             g_stats.s.n_reads += T; g_stats.s.n_ext += hc.n_ext; g_stats.s.n_lf += hc.n_lf; g_stats.s.n_sa += hc.n_sa;
@@ -999,7 +1026,7 @@ static bool pe_phase1_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
 {
     const uint32_t r0 = spec.r0;
     const int T = (int)(spec.r1 - spec.r0), L = spec.L;
-    PE_REQ(ws.ensure_reads(T, L, seeds_of_chunk.cap, ws.out_cap_hint, post_bytes_per_read(L, opt, false), false));
+    PE_REQ(ws.ensure_reads(opt, T, L, seeds_of_chunk.cap, ws.out_cap_hint, post_bytes_per_read(L, opt, false), false));
     PE_REQ(ws.ensure_seeds(std::max<int64_t>(ws.seed_cap, (int64_t)T * 16)));
     auto make_view = [&]() { return tile_view(ws, spec, read_id0, seeds_of_chunk, chunk_r0); };
     TileView tv = make_view();
@@ -1057,7 +1084,7 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
     size_t pe_zpool = 0;
     for (;;) {
         if (++attempts > 8) { fprintf(stderr, "[bwamem_hip] paired-end tile could not be sized\n"); return false; }
-        PE_REQ(ws.ensure_reads(T, L, 0, ws.out_cap_hint, post_bytes_per_read(L, opt, false), false));
+        PE_REQ(ws.ensure_reads(opt, T, L, 0, ws.out_cap_hint, post_bytes_per_read(L, opt, false), false));
         TileView tv = ws.view();
         tv.n_reads = T; tv.max_len = L; tv.read_id0 = read_id0 + pt->r0;
         tv.seq = pt->seq; tv.seq_off = pt->seq_off;
