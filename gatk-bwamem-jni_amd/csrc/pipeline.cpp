@@ -190,16 +190,17 @@ struct ReqBuf {
 // should not have to learn the same sizes again.
 struct CapHints {
     std::mutex mu;
-    double jobs_per_read = 0, zpool_per_read = 0;
+    double jobs_per_read = 0, zpool_mult = 1;       // zpool_mult: how many times the default traceback pool a tile ended up needing
     int out_cap = 512;
-    void learn(int T, int n_jobs, size_t zpool_cap, int out_cap_) {
+    void learn(int T, int n_jobs, double zpool_mult_, int out_cap_) {
         std::lock_guard<std::mutex> lk(mu);
-        if (T > 0) { jobs_per_read = std::max(jobs_per_read, 1.25 * n_jobs / T); zpool_per_read = std::max(zpool_per_read, (double)zpool_cap / T); }
+        if (T >= 64) jobs_per_read = std::max(jobs_per_read, 1.25 * n_jobs / T);
+        zpool_mult = std::min(64.0, std::max(zpool_mult, zpool_mult_));
         out_cap = std::max(out_cap, out_cap_);
     }
-    void get(int T, int& jobs, size_t& zpool, int& out_cap_) {
+    void get(int T, int& jobs, double& zpool_mult_, int& out_cap_) {
         std::lock_guard<std::mutex> lk(mu);
-        jobs = (int)std::min(2.0e9, jobs_per_read * T) + 1; zpool = (size_t)(zpool_per_read * T); out_cap_ = out_cap;
+        jobs = (int)std::min(1.0e9, jobs_per_read * T) + 1; zpool_mult_ = zpool_mult; out_cap_ = out_cap;
     }
 };
 
@@ -732,14 +733,16 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
     const int T = (int)(spec.r1 - spec.r0), L = spec.L;
     int attempts = 0, job_cap_hint = 0;
     size_t zpool_hint = (size_t)64 << 20;
-    { size_t z = 0; int oc = 0; ix->hints.get(T, job_cap_hint, z, oc); zpool_hint = std::max(zpool_hint, z); out_cap = std::max(out_cap, oc); }
+    double zmult = 1;
+    { int oc = 0; ix->hints.get(T, job_cap_hint, zmult, oc); out_cap = std::max(out_cap, oc); }
     for (;;) {
         if (++attempts > 8) { fprintf(stderr, "[bwamem_hip] tile could not be sized after 8 attempts\n"); return false; }
         if (!ws.ensure_reads(opt, T, L, seeds_of_chunk.cap, out_cap, post_bytes_per_read(L, opt, false), false)) return false;
         if (!ws.ensure_seeds(std::max<int64_t>(ws.seed_cap, (int64_t)T * 16))) return false;
         {   // the HBM pool also holds the direction nibbles of k_gcigar_lane: 20 bytes per target row of every job
             const int jc = std::max(job_cap_hint, std::max(1024, T / 4));
-            if (!ws.ensure_jobs(jc, 4 * L + 16, std::max(zpool_hint, (size_t)jc * (size_t)(2 * L + 64) * 20 + ((size_t)64 << 20)))) return false;
+            const size_t zdef = (size_t)jc * (size_t)(2 * L + 64) * 20 + ((size_t)64 << 20);
+            if (!ws.ensure_jobs(jc, 4 * L + 16, std::max(zpool_hint, (size_t)((double)zdef * zmult)))) return false;
         }
         TileView tv = tile_view(ws, spec, read_id0, seeds_of_chunk, chunk_r0);
         HIP_OK(hipMemsetAsync(ws.err.p, 0, 64, ws.stream));
@@ -791,7 +794,7 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
             fprintf(stderr, "[bwamem_hip] device error flags %d\n", err); return false;
         }
         if (!emit_tile(ws, b, tile_index, tv, out_total, to)) return false;
-        ix->hints.learn(T, n_jobs, ws.zpool_cap, out_cap);
+        ix->hints.learn(T, n_jobs, zpool_hint > ((size_t)64 << 20) ? (double)zpool_hint / ((double)std::max(job_cap_hint, std::max(1024, T / 4)) * (2.0 * L + 64) * 20 + (double)((size_t)64 << 20)) : 1.0, out_cap);
         {
             std::lock_guard<std::mutex> lk(g_stats.mu);
             g_stats.s.n_reads += T; g_stats.s.n_ext += hc.n_ext; g_stats.s.n_lf += hc.n_lf; g_stats.s.n_sa += hc.n_sa;
