@@ -438,7 +438,13 @@ void launch_gcigar(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const 
     // rows of the wave form: rings that hold the widest band mem_reg2aln asks for (opt.w << 2) -- or the whole read when that
     // is shorter.  Jobs whose band is wider still (regions with a long net indel) go to the HBM kernel behind it.
     int ring = 64;
-    { long long need = 8ll * (opt.w > 0 ? opt.w : 0) + 8; if (need > (long long)cap + 2) need = (long long)cap + 2; if (need > 16384) need = 16384; while (ring < need) ring <<= 1; }
+    {   // the widest band bwa_gen_cigar2 can take here is 4 w + 3 (w2 <= opt.w << 2, and regions are only merged across gaps of up to 4 w)
+        long long need = 8ll * (opt.w > 0 ? opt.w : 0) + 16;
+        if (need > (long long)cap + 2) need = (long long)cap + 2;
+        if (need > 4096) need = 4096;                                // 48 KB of rows at most
+        { const char* e = getenv("BWAMEM_HIP_GCIGAR_RING"); if (e && atoi(e) > 0 && atoi(e) < need) need = atoi(e); }   // (tests: force jobs over to the HBM kernel)
+        while (ring < need) ring <<= 1;
+    }
     const size_t tail = ((cap + 15) & ~(size_t)15) + (size_t)z_lds_cap + 64;
     hipLaunchKernelGGL(k_gcigar_lane<16>, dim3((n_jobs + 63) / 64), dim3(64), 0, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur);
     if (!tv.gcigar_hbm_only)

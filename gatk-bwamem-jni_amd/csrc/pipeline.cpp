@@ -75,7 +75,7 @@ static void dp_rows_policy(int lds, const MemOpt& opt, int L, bool& need_rows, b
     const bool forced = e && !strcmp(e, "hbm");
     ext_hbm = forced || extend_lds_bytes(opt, L) + 64 > (size_t)lds;
     gcigar_hbm_only = forced || (size_t)L + 4 + 3 * 1024 * 4 + 6144 + 64 > (size_t)lds;    // (the read itself next to the smallest useful rings)
-    need_rows = forced || ext_hbm || gcigar_hbm_only || (long long)L + 4 > 8ll * (opt.w > 0 ? opt.w : 0) + 8;
+    need_rows = forced || ext_hbm || gcigar_hbm_only || (long long)L + 4 > 8ll * (opt.w > 0 ? opt.w : 0) + 16 || getenv("BWAMEM_HIP_GCIGAR_RING") != nullptr;
 }
 
 struct Workspace {
