@@ -355,12 +355,18 @@ __global__ void __launch_bounds__(64, 2) k_gcigar_lane(DevIndex ix, MemOpt opt, 
 // (launched after this one whenever the tile's reads are longer than the ring).
 template <bool HBM>
 __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView tv, const DpJob* jobs, DpOut* outs, int n_jobs, uint32_t* cig_pool, int cig_cap,
-                                               uint8_t* zpool, unsigned long long zpool_cap, unsigned long long* zpool_cur, int z_lds_cap, int ring)
+                                               uint8_t* zpool, unsigned long long zpool_cap, unsigned long long* zpool_cur, int z_lds_cap, int ring,
+                                               uint8_t* slabs, unsigned long long slab_bytes, int* queue)
 {
     HIP_DYNAMIC_SHARED(int32_t, smem)
     const int lane = threadIdx.x;
-  for (int job = blockIdx.x; job < n_jobs; job += HBM ? (int)gridDim.x : n_jobs) {
-    __syncthreads();                                                   // (HBM) the previous job of this workgroup is done with the rows
+    // slabs != null (tiles of long reads): a resident grid pulls jobs from a queue and every workgroup keeps the traceback
+    // matrix of its current job in a slab of its own -- megabytes per job, but bounded by the grid, not by the job count
+  for (int job = blockIdx.x, first = 1; ; first = 0) {
+    if (slabs) { int nx = 0; if (lane == 0) nx = atomicAdd(queue, 1); job = __shfl(nx, 0); }
+    else if (!first) job += HBM ? (int)gridDim.x : n_jobs;
+    if (job >= n_jobs) break;
+    __syncthreads();                                                   // the previous job of this workgroup is done with the rows
     if (outs[job].n_cigar >= 0) continue;                              // done by k_gcigar_lane
     const DpJob jb = jobs[job];
     const AlnReg ar = tv.regs[tv.seed_off[jb.read] + jb.reg];
@@ -404,7 +410,8 @@ __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView
             const int n_col = l_query < 2 * w + 1 ? l_query : 2 * w + 1;
             const unsigned long long need = (unsigned long long)n_col * (unsigned long long)rlen;
             uint8_t* z = z_lds;
-            if (need > (unsigned long long)z_lds_cap) {                  // traceback matrix too big for LDS: bump-allocate HBM
+            if (need > (unsigned long long)z_lds_cap && slabs && need <= slab_bytes) z = slabs + (unsigned long long)blockIdx.x * slab_bytes;
+            else if (need > (unsigned long long)z_lds_cap) {             // traceback matrix too big for LDS: bump-allocate HBM
                 unsigned long long at = 0;
                 if (lane == 0) at = atomicAdd(zpool_cur, (need + 63ull) & ~63ull);
                 at = __shfl(at, 0);
@@ -428,8 +435,17 @@ __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView
   }
 }
 
+// bytes of one traceback slab of the wave form for tiles of long reads (0: none -- short reads keep theirs in LDS / the pool)
+size_t gcigar_slab_bytes(const MemOpt& opt, int max_len)
+{
+    if (max_len <= 1000) return 0;
+    const size_t w_max = 4 * (size_t)(opt.w > 0 ? opt.w : 0) + 3;
+    return ((2 * w_max + 1) * ((size_t)max_len + 2 * w_max + 64) + 255) & ~(size_t)255;
+}
+int gcigar_slab_grid(const DevIndex& ix, int n_jobs) { const int g = (ix.n_cu > 0 ? ix.n_cu : 256) * 4; return n_jobs < g ? n_jobs : g; }
+
 void launch_gcigar(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, int n_jobs, const void* jobs, void* outs, uint32_t* cig_pool, int cig_cap,
-                   uint8_t* zpool, unsigned long long zpool_cap, unsigned long long* zpool_cur)
+                   uint8_t* zpool, unsigned long long zpool_cap, unsigned long long* zpool_cur, uint8_t* slabs, size_t slab_bytes, int* queue)
 {
     if (n_jobs <= 0) return;
     int z_lds_cap = 6144;                                            // covers bands of ~40 columns x 150 rows; larger matrices go to the HBM pool
@@ -447,10 +463,14 @@ void launch_gcigar(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const 
     }
     const size_t tail = ((cap + 15) & ~(size_t)15) + (size_t)z_lds_cap + 64;
     hipLaunchKernelGGL(k_gcigar_lane<16>, dim3((n_jobs + 63) / 64), dim3(64), 0, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur);
-    if (!tv.gcigar_hbm_only)
-        hipLaunchKernelGGL(k_gcigar<false>, dim3(n_jobs), dim3(64), 3 * (size_t)ring * sizeof(int32_t) + tail, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap, ring);
+    if (!tv.gcigar_hbm_only) {
+        if (!slab_bytes) slabs = nullptr;
+        const int grid = slabs ? gcigar_slab_grid(ix, n_jobs) : n_jobs;
+        hipLaunchKernelGGL(k_gcigar<false>, dim3(grid), dim3(64), 3 * (size_t)ring * sizeof(int32_t) + tail, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap, ring,
+                           slabs, (unsigned long long)slab_bytes, queue);
+    }
     if (tv.dp_rows) {
         const int grid = n_jobs < tv.dp_rows_blocks ? n_jobs : tv.dp_rows_blocks;
-        hipLaunchKernelGGL(k_gcigar<true>, dim3(grid), dim3(64), tail, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap, 0);
+        hipLaunchKernelGGL(k_gcigar<true>, dim3(grid), dim3(64), tail, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap, 0, (uint8_t*)nullptr, 0ull, (int*)nullptr);
     }
 }

@@ -10,10 +10,17 @@
 #include "kernels.h"
 #include "post_common.h"
 
-__global__ void __launch_bounds__(64, 6) k_post1(DevIndex ix, MemOpt opt, TileView tv)
+// WAVE_PER_READ = false: one lane per read.  true (tiles of long reads): one wavefront per read -- sixty-four times the waves
+// in flight for this latency-bound stage -- with lane 0 doing the updates and the banded global alignments of region
+// patching spread across the lanes (sort_dedup_patch_wave / global_score_wave; rings in dynamic LDS).
+template <bool WAVE_PER_READ>
+__global__ void __launch_bounds__(64, 6) k_post1(DevIndex ix, MemOpt opt, TileView tv, int ring)
 {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    HIP_DYNAMIC_SHARED(int32_t, smem)
+    const int r = WAVE_PER_READ ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (r >= tv.n_reads) return;
+    const bool writer = !WAVE_PER_READ || threadIdx.x == 0;
+    WaveDp wd; wd.eh_h = smem; wd.eh_e = smem + ring; wd.tmpM = smem + 2 * ring; wd.rm = ring - 1; wd.lane = (int)threadIdx.x;
     PostScratch S = post_scratch_for(tv, r);
     const uint8_t* query = tv.seq + tv.seq_off[r];
     AlnReg* a = tv.regs + tv.seed_off[r];
@@ -25,18 +32,22 @@ __global__ void __launch_bounds__(64, 6) k_post1(DevIndex ix, MemOpt opt, TileVi
             bad = a[i].qb < 0 || a[i].qe < a[i].qb || a[i].qe > l_query || a[i].rb < 0 || a[i].re < a[i].rb || a[i].re > ix.l_pac << 1
                || a[i].re - a[i].rb > 4 * (int64_t)l_query + 1024 || a[i].rid < 0 || a[i].rid >= ix.n_seqs;
         if (bad) {
-            if (!(atomicOr(tv.err, ERR_BAD_REG) & ERR_BAD_REG)) { tv.err[1] = r; tv.err[2] = n0; if (n0 > 0) { tv.err[3] = a[0].qb; tv.err[4] = a[0].qe; tv.err[5] = (int)a[0].rb; tv.err[6] = (int)a[0].re; tv.err[7] = a[0].score; } }
-            tv.n_regs[r] = 0;
+            if (writer && !(atomicOr(tv.err, ERR_BAD_REG) & ERR_BAD_REG)) { tv.err[1] = r; tv.err[2] = n0; if (n0 > 0) { tv.err[3] = a[0].qb; tv.err[4] = a[0].qe; tv.err[5] = (int)a[0].rb; tv.err[6] = (int)a[0].re; tv.err[7] = a[0].score; } }
+            if (WAVE_PER_READ) __syncthreads();
+            if (writer) tv.n_regs[r] = 0;
             return;
         }
     }
     if (tv.debug & 0xff) printf("[k] post1 read %d n=%d\n", r, tv.n_regs[r]);
-    int n = sort_dedup_patch(ix, opt, S, query, tv.n_regs[r], a, tv.debug & 0xff);
+    const int n_in = tv.n_regs[r];
+    if (WAVE_PER_READ) __syncthreads();                              // every lane has read the count before lane 0 replaces it
+    int n = WAVE_PER_READ ? sort_dedup_patch_wave(ix, opt, S, query, n_in, a, wd) : sort_dedup_patch(ix, opt, S, query, n_in, a, tv.debug & 0xff);
     if (tv.debug & 0xff) printf("[k] post1 read %d done n=%d\n", r, n);
-    for (int i = 0; i < n; ++i)
-        if (a[i].rid >= 0 && ix.ann_is_alt[a[i].rid]) a[i].is_alt = 1;
-    tv.n_regs[r] = n;
-    if (S.err) atomicOr(tv.err, S.err);
+    if (writer)
+        for (int i = 0; i < n; ++i)
+            if (a[i].rid >= 0 && ix.ann_is_alt[a[i].rid]) a[i].is_alt = 1;
+    if (writer) tv.n_regs[r] = n;
+    if (S.err && writer) atomicOr(tv.err, S.err);
 }
 
 // ------------------------------------------------------------------ single-end finalisation
@@ -113,7 +124,16 @@ __global__ void k_pack(TileView tv, uint8_t* dst)
 void launch_post1(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv)
 {
     if (tv.n_reads <= 0) return;
-    hipLaunchKernelGGL(k_post1, dim3((tv.n_reads + 63) / 64), dim3(64), 0, st, ix, opt, tv);
+    if (tv.max_len > 1000) {                                         // long reads: a wavefront per read
+        int ring = 64;
+        long long need = 8ll * (opt.w > 0 ? opt.w : 0) + 16;
+        if (need > (long long)tv.max_len + 4) need = (long long)tv.max_len + 4;
+        if (need > 4096) need = 4096;
+        while (ring < need) ring <<= 1;
+        hipLaunchKernelGGL(k_post1<true>, dim3(tv.n_reads), dim3(64), 3 * (size_t)ring * sizeof(int32_t), st, ix, opt, tv, ring);
+        return;
+    }
+    hipLaunchKernelGGL(k_post1<false>, dim3((tv.n_reads + 63) / 64), dim3(64), 0, st, ix, opt, tv, 64);
 }
 void launch_final_prep(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv)
 {

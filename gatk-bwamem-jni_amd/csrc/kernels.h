@@ -22,8 +22,10 @@ size_t extend_lds_bytes(const MemOpt& opt, int max_len);       // dynamic LDS k_
 void launch_extend(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 void launch_post1(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 void launch_final_prep(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
+size_t gcigar_slab_bytes(const MemOpt& opt, int max_len);      // traceback slab per resident workgroup of the wave form (long reads), 0 = none
+int gcigar_slab_grid(const DevIndex& ix, int n_jobs);
 void launch_gcigar(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, int n_jobs, const void* jobs, void* outs, uint32_t* cig_pool, int cig_cap,
-                   uint8_t* zpool, unsigned long long zpool_cap, unsigned long long* zpool_cur);
+                   uint8_t* zpool, unsigned long long zpool_cap, unsigned long long* zpool_cur, uint8_t* slabs, size_t slab_bytes, int* queue);
 void launch_final_se(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, const void* job_out, const uint32_t* job_cig, int cig_cap);
 void launch_pack(hipStream_t st, const TileView& tv, uint8_t* dst);
 

@@ -86,7 +86,8 @@ struct Workspace {
     DevBuf out, out_len, out_off, post, err, cnt;
     DevBuf dp_rows; int dp_rows_blocks = 0;          // DP rows of k_extend / k_gcigar in global memory (dp_rows_policy)
     bool ext_hbm = false, gcigar_hbm_only = false;
-    DevBuf jobs, job_out, job_cig, job_cnt, zpool;   // single-end global-alignment jobs
+    DevBuf jobs, job_out, job_cig, job_cnt, zpool, zslabs;   // global-alignment jobs; zslabs: traceback slabs of k_gcigar's resident grid (long reads)
+    size_t zslab_bytes = 0;
     int job_cap = 0, job_cig_cap = 0; size_t zpool_cap = 0;
     int out_cap_hint = 512;                           // bytes per read of the output staging slots (grown on overflow, kept across tiles)
     int dev_lds = 0;                                  // LDS per workgroup of the device this workspace lives on
@@ -128,7 +129,7 @@ struct Workspace {
     void release() {
         DevBuf* all[] = { &intv, &n_intv, &smem, &l_rep, &n_seeds, &seed_off, &intv_seed_off, &seeds, &seed_rid, &cseeds, &chains,
                           &chain_store, &n_chains, &bt_nodes, &srt, &regs, &n_regs, &out, &out_len, &out_off, &post, &err, &cnt, &dp_rows,
-                          &jobs, &job_out, &job_cig, &job_cnt, &zpool, &pe_dir, &pe_is, &pe_caps, &pe_reg_off2, &pe_regs2, &pe_ints2, &pe_vpool, &pe_scratch, &pe_states,
+                          &jobs, &job_out, &job_cig, &job_cnt, &zpool, &zslabs, &pe_dir, &pe_is, &pe_caps, &pe_reg_off2, &pe_regs2, &pe_ints2, &pe_vpool, &pe_scratch, &pe_states,
                           &pe_rescue[0], &pe_rescue[1], &pe_rescue[2], &scan_tmp, &packed };
         for (DevBuf* b : all) b->release();
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
@@ -741,7 +742,8 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
         if (!ws.ensure_seeds(std::max<int64_t>(ws.seed_cap, (int64_t)T * 16))) return false;
         {   // the HBM pool also holds the direction nibbles of k_gcigar_lane: 20 bytes per target row of every job
             const int jc = std::max(job_cap_hint, std::max(1024, T / 4));
-            const size_t zdef = (size_t)jc * (size_t)(2 * L + 64) * 20 + ((size_t)64 << 20);
+            size_t zdef = (size_t)jc * (size_t)(2 * L + 64) * 20 + ((size_t)64 << 20);
+            if (gcigar_slab_bytes(opt, L)) zdef = std::min(zdef, (size_t)1 << 30);          // long reads: the wave form's matrices live in its slabs
             if (!ws.ensure_jobs(jc, 4 * L + 16, std::max(zpool_hint, (size_t)((double)zdef * zmult)))) return false;
         }
         TileView tv = tile_view(ws, spec, read_id0, seeds_of_chunk, chunk_r0);
@@ -766,13 +768,29 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
         TIMED(ws, K_EXTEND, launch_extend(ws.stream, ix->d, opt, tv));
         if (getenv("BWAMEM_HIP_DUMP") && T <= 64) debug_dump(ws, tv, T);
         TIMED(ws, K_POST, launch_post1(ws.stream, ix->d, opt, tv));
+        if (L > 1000) {
+            // long reads: regions per read vary by orders of magnitude, and a tile re-run costs seconds.  Every job is a region,
+            // so the region count (known now) bounds the job list: size it before the jobs are listed instead of retrying
+            int64_t n_regs_total = 0;
+            TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_regs, tv.out_off, T, ws.scan_tmp.as<int64_t>()));
+            HIP_OK(hipMemcpyAsync(&n_regs_total, tv.out_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
+            HIP_OK(hipStreamSynchronize(ws.stream));
+            if (n_regs_total > ws.job_cap) {
+                if (!ws.ensure_jobs((int)std::min<int64_t>(n_regs_total + 64, 0x7fffffff), 4 * L + 16, ws.zpool_cap)) return false;
+                tv = tile_view(ws, spec, read_id0, seeds_of_chunk, chunk_r0);
+                HIP_OK(hipMemsetAsync(ws.job_cnt.p, 0, 64, ws.stream));
+            }
+        }
         TIMED(ws, K_FINAL, launch_final_prep(ws.stream, ix->d, opt, tv));
         int32_t n_jobs = 0;
         HIP_OK(hipMemcpyAsync(&n_jobs, tv.job_cnt, 4, hipMemcpyDeviceToHost, ws.stream));
         HIP_OK(hipStreamSynchronize(ws.stream));
         if (n_jobs > ws.job_cap) { job_cap_hint = n_jobs + n_jobs / 4; { std::lock_guard<std::mutex> lk(g_stats.mu); ++g_stats.s.n_retries; } continue; }
+        ws.zslab_bytes = gcigar_slab_bytes(opt, L);
+        if (ws.zslab_bytes && !ws.zslabs.ensure(ws.zslab_bytes * (size_t)gcigar_slab_grid(ix->d, 1 << 30))) return false;
         TIMED(ws, K_FINAL, launch_gcigar(ws.stream, ix->d, opt, tv, n_jobs, ws.jobs.p, ws.job_out.p, ws.job_cig.as<uint32_t>(), ws.job_cig_cap,
-                                         ws.zpool.as<uint8_t>(), (unsigned long long)ws.zpool_cap, (unsigned long long*)(ws.job_cnt.as<int32_t>() + 2)));
+                                         ws.zpool.as<uint8_t>(), (unsigned long long)ws.zpool_cap, (unsigned long long*)(ws.job_cnt.as<int32_t>() + 2),
+                                         ws.zslabs.as<uint8_t>(), ws.zslab_bytes, ws.job_cnt.as<int32_t>() + 4));
         TIMED(ws, K_FINAL, launch_final_se(ws.stream, ix->d, opt, tv, ws.job_out.p, ws.job_cig.as<uint32_t>(), ws.job_cig_cap));
         TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.out_len, tv.out_off, T, ws.scan_tmp.as<int64_t>()));
         int64_t out_total = 0;
@@ -1138,8 +1156,11 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
         {
             TileView tvj = tv;                              // the job kernels address a region as regs[seed_off[read] + index]
             tvj.regs = regs2; tvj.seed_off = reg_off2;
+            ws.zslab_bytes = gcigar_slab_bytes(opt, L);
+            PE_REQ(!ws.zslab_bytes || ws.zslabs.ensure(ws.zslab_bytes * (size_t)gcigar_slab_grid(ix->d, 1 << 30)));
             TIMED(ws, K_FINAL, launch_gcigar(ws.stream, ix->d, opt, tvj, n_jobs, ws.jobs.p, ws.job_out.p, ws.job_cig.as<uint32_t>(), ws.job_cig_cap,
-                                             ws.zpool.as<uint8_t>(), (unsigned long long)ws.zpool_cap, (unsigned long long*)(ws.job_cnt.as<int32_t>() + 2)));
+                                             ws.zpool.as<uint8_t>(), (unsigned long long)ws.zpool_cap, (unsigned long long*)(ws.job_cnt.as<int32_t>() + 2),
+                                             ws.zslabs.as<uint8_t>(), ws.zslab_bytes, ws.job_cnt.as<int32_t>() + 4));
         }
         TIMED(ws, K_FINAL, launch_pe_out(ws.stream, ix->d, opt, tv, regs2, reg_off2, tv.n_regs, ws.pe_ints2.as<int32_t>(), pes, ws.pe_states.p,
                                          ws.job_out.p, ws.job_cig.as<uint32_t>(), ws.job_cig_cap));

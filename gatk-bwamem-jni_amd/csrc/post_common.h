@@ -3,6 +3,7 @@
 // Behavioural contract: SURVEY.md rows a14-a18 (see k_post.hip for the upstream names).
 #pragma once
 #include "dev_common.h"
+#include "wave_ops.h"
 
 #define INT_MAX_ 2147483647
 #define MINUS_INF (-0x40000000)
@@ -177,6 +178,75 @@ DEV int global_dp(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const S
     return score;
 }
 
+// The same alignment, score only, by a whole wavefront: for callers in which all 64 lanes of a one-wave workgroup run this
+// code in lockstep on the same read (k_post1_wave, long reads), where a lane-serial DP over thousands of rows would leave
+// 63 lanes idle.  Rows are rings in LDS around the band (cf. ExtLds in k_extend.hip); row i writes index i + w + 1 before
+// row i + 1 reads it, so only indices 0 .. w + 1 are initialised here.  Same recurrence and tie rules as global_dp.
+struct WaveDp { int32_t* eh_h; int32_t* eh_e; int32_t* tmpM; int rm; int lane; };
+DEV int global_score_wave(const DevIndex& ix, const MemOpt& opt, const WaveDp& L, const SeqAcc& A, int w)
+{
+    const int lane = L.lane, RM = L.rm;
+    const int qlen = A.qlen, tlen = A.tlen;
+    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int NEG = -2000000000;
+    const ScoreTab ST = score_tab(opt);
+    __syncthreads();
+    for (int j = lane; j <= qlen && j <= w + 1; j += WAVE) {
+        L.eh_h[j & RM] = j == 0 ? 0 : (j <= w ? -(o_ins + e_ins * j) : MINUS_INF);
+        L.eh_e[j & RM] = MINUS_INF;
+    }
+    int tch = 4;
+    __syncthreads();
+    for (int i = 0; i < tlen; ++i) {
+        if ((i & 63) == 0) { int ii = i + lane; tch = ii < tlen ? acc_t(ix, A, ii) : 4; }
+        const int tb = wave_bcast(tch, i & 63);
+        const int ms0 = score_at(ST.p[0], ST.n[0], tb), ms1 = score_at(ST.p[1], ST.n[1], tb), ms2 = score_at(ST.p[2], ST.n[2], tb), ms3 = score_at(ST.p[3], ST.n[3], tb), ms4 = score_at(ST.p[4], ST.n[4], tb);
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        const int h1i = beg == 0 ? -(o_del + e_del * (i + 1)) : MINUS_INF;
+        for (int c = beg; c < end; c += WAVE) {                     // M(i,j) from row i-1, before any cell of the row is overwritten
+            const int j = c + lane;
+            if (j < end) {
+                const int qc = acc_q(A, j);
+                const int sc = qc == 0 ? ms0 : qc == 1 ? ms1 : qc == 2 ? ms2 : qc == 3 ? ms3 : ms4;
+                L.tmpM[j & RM] = L.eh_h[j & RM] + sc;
+            }
+        }
+        __syncthreads();
+        int fcarry = MINUS_INF;
+        for (int c = beg; c < end; c += WAVE) {                     // F by scan, H, E
+            const int j = c + lane;
+            const bool act = j < end;
+            const int m = act ? L.tmpM[j & RM] : 0;
+            const int e = act ? L.eh_e[j & RM] : 0;
+            const int tins = m - oe_ins;
+            const int U = act ? tins + j * e_ins : NEG;
+            const int P = wave_prefix_max(U, lane);
+            const int Pex = __shfl_up(P, 1);
+            int f = fcarry - (j - c) * e_ins;
+            if (lane > 0) { const int g = Pex - (j - 1) * e_ins; f = f > g ? f : g; }
+            int h = m >= e ? m : e;
+            h = h >= f ? h : f;
+            const int t = m - oe_del;
+            int e2 = e - e_del;
+            e2 = e2 > t ? e2 : t;
+            const int Plast = wave_bcast(P, 63);
+            { const int f1 = fcarry - WAVE * e_ins, f2 = Plast - (c + 63) * e_ins; fcarry = f1 > f2 ? f1 : f2; }
+            if (act) { L.eh_e[j & RM] = e2; L.eh_h[(j + 1) & RM] = h; }
+        }
+        if (lane == 0) {
+            if (end > beg) L.eh_h[beg & RM] = h1i;
+            else L.eh_h[end & RM] = h1i;
+            L.eh_e[end & RM] = MINUS_INF;
+        }
+        __syncthreads();
+    }
+    const int score = L.eh_h[qlen & RM];
+    __syncthreads();
+    return score;
+}
+
 // NM and MD of the CIGAR in S.cig[1..1+n_cig) (the tail of upstream bwa_gen_cigar2): MD lands NUL-terminated in S.md
 DEV void cigar_nm_md(const DevIndex& ix, PostScratch& S, const SeqAcc& A, int n_cig, bool fwd_strand, int* NM, int* l_md)
 {
@@ -213,7 +283,7 @@ DEV void cigar_nm_md(const DevIndex& ix, PostScratch& S, const SeqAcc& A, int n_
 // bwa_gen_cigar2: returns false when upstream would return a NULL cigar.  CIGAR lands in
 // S.cig[1..1+n), MD in S.md (NUL-terminated, length *l_md) when want_cigar.
 DEV bool gen_cigar2(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int w_, int l_query, const uint8_t* query,
-                    int64_t rb, int64_t re, int* score, bool want_cigar, int* n_cigar, int* NM, int* l_md = 0)
+                    int64_t rb, int64_t re, int* score, bool want_cigar, int* n_cigar, int* NM, int* l_md = 0, const WaveDp* wd = nullptr)
 {
     const int64_t l_pac = ix.l_pac;
     if (n_cigar) *n_cigar = 0;
@@ -247,7 +317,9 @@ DEV bool gen_cigar2(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int w
         w = w < w_ ? w : w_;
         min_w = d + 3;
         w = w > min_w ? w : min_w;
-        *score = global_dp(ix, opt, S, A, w, want_cigar, &n_cig);
+        // a wavefront running this in lockstep aligns across its lanes when the band fits its rings (score only)
+        if (wd && !want_cigar && (2 * w + 4 <= wd->rm + 1 || l_query + 2 <= wd->rm + 1)) *score = global_score_wave(ix, opt, *wd, A, w);
+        else *score = global_dp(ix, opt, S, A, w, want_cigar, &n_cig);
     }
     if (want_cigar) {
         if (n_cigar) *n_cigar = n_cig;
@@ -382,7 +454,7 @@ struct RegSLt  { __device__ bool operator()(const AlnReg& a, const AlnReg& b) co
     return a.score > b.score || (a.score == b.score && (a.rb < b.rb || (a.rb == b.rb && a.qb < b.qb))); } };
 
 // mem_patch_reg: can two colinear regions be merged into one global alignment?
-DEV int patch_reg(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const uint8_t* query, const AlnReg& a, const AlnReg& b, int* _w)
+DEV int patch_reg(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const uint8_t* query, const AlnReg& a, const AlnReg& b, int* _w, const WaveDp* wd = nullptr)
 {
     if (a.rb < ix.l_pac && b.rb >= ix.l_pac) return 0;
     if (a.qb >= b.qb || a.qe >= b.qe || a.re >= b.re) return 0;
@@ -396,7 +468,7 @@ DEV int patch_reg(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const u
     w += a.w + b.w;
     w = w < opt.w << 2 ? w : opt.w << 2;
     int score = 0;
-    gen_cigar2(ix, opt, S, w, b.qe - a.qb, query + a.qb, a.rb, b.re, &score, false, 0, 0);
+    gen_cigar2(ix, opt, S, w, b.qe - a.qb, query + a.qb, a.rb, b.re, &score, false, 0, 0, 0, wd);
     int q_s = (int)((double)(b.qe - a.qb) / ((b.qe - b.qb) + (a.qe - a.qb)) * (b.score + a.score) + .499);
     int r_s = (int)((double)(b.re - a.rb) / ((b.re - b.rb) + (a.re - a.rb)) * (b.score + a.score) + .499);
     if ((double)score / (q_s > r_s ? q_s : r_s) < 0.90f) return 0;
@@ -454,6 +526,68 @@ DEV int sort_dedup_patch(const DevIndex& ix, const MemOpt& opt, PostScratch& S, 
     return m;
 }
 
+
+// The same procedure run by a whole wavefront on one read (k_post1<true>, long reads): every lane follows the control flow
+// (all decisions are read from memory that only lane 0 writes, with a barrier on either side of each write), lane 0 does the
+// updates, and the patch alignments run across the lanes.
+DEV int sort_dedup_patch_wave(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const uint8_t* query, int n, AlnReg* a, const WaveDp& wd)
+{
+    const bool w0 = wd.lane == 0;
+    int m = n, i, j;
+    if (n <= 1) return n;
+    __syncthreads();
+    if (w0) { ks_introsort((size_t)n, a, RegReLt()); for (i = 0; i < n; ++i) a[i].n_comp = 1; }
+    __syncthreads();
+    for (i = 1; i < n; ++i) {
+        AlnReg* p = &a[i];
+        if (p->rid != a[i - 1].rid || p->rb >= a[i - 1].re + opt.max_chain_gap) continue;
+        for (j = i - 1; j >= 0 && p->rid == a[j].rid && p->rb < a[j].re + opt.max_chain_gap; --j) {
+            AlnReg* q = &a[j];
+            int64_t orr, oq, mr, mq;
+            int score, w;
+            if (q->qe == q->qb) continue;
+            orr = q->re - p->rb;
+            oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
+            mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
+            mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
+            if ((float)orr > opt.mask_level_redun * (float)mr && (float)oq > opt.mask_level_redun * (float)mq) {
+                const bool drop_p = p->score < q->score;
+                __syncthreads();
+                if (w0) { if (drop_p) p->qe = p->qb; else q->qe = q->qb; }
+                __syncthreads();
+                if (drop_p) break;
+            } else if (query && q->rb < p->rb && (score = patch_reg(ix, opt, S, query, *q, *p, &w, &wd)) > 0) {
+                __syncthreads();
+                if (w0) {
+                    p->n_comp += q->n_comp + 1;
+                    p->seedcov = p->seedcov > q->seedcov ? p->seedcov : q->seedcov;
+                    p->sub = p->sub > q->sub ? p->sub : q->sub;
+                    p->csub = p->csub > q->csub ? p->csub : q->csub;
+                    p->qb = q->qb; p->rb = q->rb;
+                    p->truesc = p->score = score;
+                    p->w = w;
+                    q->qb = q->qe;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+    if (w0) {
+        for (i = 0, m = 0; i < n; ++i)
+            if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
+        n = m;
+        ks_introsort((size_t)n, a, RegSLt());
+        for (i = 1; i < n; ++i)
+            if (a[i].score == a[i - 1].score && a[i].rb == a[i - 1].rb && a[i].qb == a[i - 1].qb)
+                a[i].qe = a[i].qb;
+        for (i = 1, m = n < 1 ? n : 1; i < n; ++i)
+            if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
+    }
+    m = __shfl(m, 0);
+    __syncthreads();
+    return m;
+}
 
 // ------------------------------------------------------------------ primary marking (a14)
 struct RegHLt  { __device__ bool operator()(const AlnReg& a, const AlnReg& b) const {

@@ -74,6 +74,13 @@ def test_emu_long_reads_seed_rescoring(emu, oracle, small_genome):
     seqs, img = small_genome
     reads = B.simulate_reads(seqs, 2, length=800, seed=5, sub=0.06, indel=0.02)
     _cmp(emu, oracle, img, reads)
+    # beyond 1000 bases region post-processing runs one wavefront per read (k_post1<true>): a 45-base deletion makes it merge
+    # two regions through the wave-parallel patch alignment
+    g = seqs[0][1]
+    rd = bytearray(g[20000:20620] + g[20665:21300])
+    for p in range(50, len(rd), 173):
+        rd[p] = ord("ACGT"[("ACGT".index(chr(rd[p])) + 1) % 4]) if chr(rd[p]) in "ACGT" else rd[p]
+    _cmp(emu, oracle, img, [bytes(rd), B.revcomp(bytes(rd))])
 
 
 def test_emu_seed_work_queue_and_spill(emu, oracle, small_genome, monkeypatch):
