@@ -205,6 +205,84 @@ static __device__ int global_wave_diag(const DevIndex& ix, const MemOpt& opt, co
     return score;
 }
 
+// The diagonal form for bands of up to 64 NCH columns (long reads: 2w + 1 runs to several hundred): slot s = 64 c + lane of
+// chunk c owns column i - w + s of row i.  Same recurrence, tie rules and direction bytes as above; the max-plus prefix
+// carries from chunk to chunk through a scalar, the E and query shifts take the first lane of the next chunk as their fill.
+// No LDS rows, no barriers: one DPP scan per chunk and row.
+template <int NCH>
+static __device__ int global_wave_diag_n(const DevIndex& ix, const MemOpt& opt, const uint8_t* sq, int lane, const SeqAcc& A, int w,
+                                         uint8_t* z, int n_col, uint32_t* cigar, int cig_cap, int* n_cigar, int& err, uint8_t* tile)
+{
+    const int qlen = A.qlen, tlen = A.tlen;
+    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const ScoreTab ST = score_tab(opt);
+    int hd[NCH], e[NCH], qv[NCH], hrow[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int j0 = c * 64 + lane - w;
+        hd[c] = j0 == 0 ? 0 : (j0 > 0 && j0 <= w ? -(o_ins + e_ins * j0) : MINUS_INF);   // H(-1, j-1): upstream's initial eh[j].h
+        e[c] = MINUS_INF; hrow[c] = MINUS_INF;
+        qv[c] = j0 >= 0 && j0 < qlen ? sq[j0] : 4;
+    }
+    int tch = 4;
+    for (int i = 0; i < tlen; ++i) {
+        if ((i & 63) == 0) { int ii = i + lane; tch = ii < tlen ? acc_t(ix, A, ii) : 4; }
+        const int tb = wave_readlane(tch, i & 63);
+        const int ms0 = score_at(ST.p[0], ST.n[0], tb), ms1 = score_at(ST.p[1], ST.n[1], tb), ms2 = score_at(ST.p[2], ST.n[2], tb), ms3 = score_at(ST.p[3], ST.n[3], tb), ms4 = score_at(ST.p[4], ST.n[4], tb);
+        const int inj = i + 64 * NCH - w;                            // query position entering the last slot for the next row
+        const int qin = inj >= 0 && inj < qlen ? sq[inj] : 4;
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        const int lb = beg - (i - w);                                // first slot of the band in this row
+        uint8_t* zi = z + (int64_t)i * n_col;
+        int pall = NEG_SCAN;                                         // best tins + s e_ins over the chunks to the left
+        int e2s[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int s = c * 64 + lane, j = i - w + s;
+            const bool act = j >= beg && j < end;
+            const int q = qv[c];
+            const int sc = q == 0 ? ms0 : q == 1 ? ms1 : q == 2 ? ms2 : q == 3 ? ms3 : ms4;
+            const int m = hd[c] + sc;
+            const int tins = m - oe_ins;
+            const int U = act ? tins + s * e_ins : NEG_SCAN;
+            const int P = dpp_prefix_max(U, NEG_SCAN);
+            int Pex = dpp_shr1(P, NEG_SCAN);
+            Pex = Pex > pall ? Pex : pall;
+            int f = MINUS_INF - (s - lb) * e_ins;
+            { const int g = Pex - (s - 1) * e_ins; f = f > g ? f : g; }
+            int d = m >= e[c] ? 0 : 1;
+            int h = m >= e[c] ? m : e[c];
+            d = h >= f ? d : 2;
+            h = h >= f ? h : f;
+            const int t = m - oe_del;
+            int e2 = e[c] - e_del;
+            d |= e2 > t ? 1 << 2 : 0;
+            e2 = e2 > t ? e2 : t;
+            d |= (f - e_ins) > tins ? 2 << 4 : 0;
+            if (act) zi[s - lb] = (uint8_t)d;
+            hd[c] = act ? h : (j == -1 ? -(o_del + e_del * (i + 1)) : MINUS_INF);   // the lane moves one column to the right along its diagonal
+            hrow[c] = h;
+            e2s[c] = act ? e2 : MINUS_INF;
+            { const int tot = wave_readlane(P, 63); pall = pall > tot ? pall : tot; }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int efill = c + 1 < NCH ? wave_readlane(e2s[c + 1 < NCH ? c + 1 : c], 0) : MINUS_INF;
+            const int qfill = c + 1 < NCH ? wave_readlane(qv[c + 1 < NCH ? c + 1 : c], 0) : qin;
+            e[c] = dpp_shl1(e2s[c], efill);
+            qv[c] = dpp_shl1(qv[c], qfill);
+        }
+    }
+    const int l_end = qlen - 1 - (tlen - 1 - w);                     // H(tlen-1, qlen-1); the caller checked that slot is in the band
+    int score = MINUS_INF;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) if ((l_end >> 6) == c) score = wave_bcast(hrow[c], l_end & 63);
+    *n_cigar = traceback(z, n_col, w, tlen, qlen, lane, cigar, cig_cap, err, tile);
+    return score;
+}
+
 // Lane-per-job form for narrow bands (w <= WMAX: the regions with three or four mismatches, i.e. most jobs).  The wave
 // forms above spend ~100 vector instructions per row on a band that fills a third of the lanes.  Here every lane runs
 // the scalar recurrence for its own job with the whole band in registers: slot l of a lane holds column i - w + l of the
@@ -406,7 +484,6 @@ __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView
             w = w < w2 ? w : w2;
             min_w = d + 3;
             w = w > min_w ? w : min_w;
-            if (!HBM && 2 * w + 4 > ring && l_query + 2 > ring) { deferred = true; break; }
             const int n_col = l_query < 2 * w + 1 ? l_query : 2 * w + 1;
             const unsigned long long need = (unsigned long long)n_col * (unsigned long long)rlen;
             uint8_t* z = z_lds;
@@ -420,7 +497,14 @@ __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView
             }
             const int l_end = l_query - 1 - (rlen - 1 - w);            // lane of the final cell in the diagonal form
             uint8_t* tile = z == z_lds || z_lds_cap < 4096 ? nullptr : z_lds;   // a matrix in global memory is walked through 64 x 64 tiles staged where the small ones live
-            if (2 * w + 1 <= WAVE && l_end >= 0 && l_end <= 2 * w) score = global_wave_diag(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
+            const bool diag_ok = l_end >= 0 && l_end <= 2 * w;
+            const int nch = (2 * w + 1 + 63) >> 6;
+            if (!HBM && !(diag_ok && nch <= 13) && 2 * w + 4 > ring && l_query + 2 > ring) { deferred = true; break; }   // needs rows longer than the rings
+            if (diag_ok && nch <= 1) score = global_wave_diag(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
+            else if (diag_ok && nch <= 2) score = global_wave_diag_n<2>(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
+            else if (diag_ok && nch <= 4) score = global_wave_diag_n<4>(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
+            else if (diag_ok && nch <= 7) score = global_wave_diag_n<7>(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
+            else if (diag_ok && nch <= 13) score = global_wave_diag_n<13>(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
             else score = global_wave(ix, opt, L, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
             if (score == last_sc || w2 == opt.w << 2) break;
             last_sc = score;
@@ -442,7 +526,7 @@ size_t gcigar_slab_bytes(const MemOpt& opt, int max_len)
     const size_t w_max = 4 * (size_t)(opt.w > 0 ? opt.w : 0) + 3;
     return ((2 * w_max + 1) * ((size_t)max_len + 2 * w_max + 64) + 255) & ~(size_t)255;
 }
-int gcigar_slab_grid(const DevIndex& ix, int n_jobs) { const int g = (ix.n_cu > 0 ? ix.n_cu : 256) * 4; return n_jobs < g ? n_jobs : g; }
+int gcigar_slab_grid(const DevIndex& ix, int n_jobs) { const int g = (ix.n_cu > 0 ? ix.n_cu : 256) * 8; return n_jobs < g ? n_jobs : g; }
 
 void launch_gcigar(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, int n_jobs, const void* jobs, void* outs, uint32_t* cig_pool, int cig_cap,
                    uint8_t* zpool, unsigned long long zpool_cap, unsigned long long* zpool_cur, uint8_t* slabs, size_t slab_bytes, int* queue)
@@ -459,6 +543,7 @@ void launch_gcigar(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const 
         if (need > (long long)cap + 2) need = (long long)cap + 2;
         if (need > 4096) need = 4096;                                // 48 KB of rows at most
         { const char* e = getenv("BWAMEM_HIP_GCIGAR_RING"); if (e && atoi(e) > 0 && atoi(e) < need) need = atoi(e); }   // (tests: force jobs over to the HBM kernel)
+        if (slab_bytes) need = 64;                                   // long reads: the register forms cover bands of up to 832 columns; the rest goes to the HBM kernel
         while (ring < need) ring <<= 1;
     }
     const size_t tail = ((cap + 15) & ~(size_t)15) + (size_t)z_lds_cap + 64;
