@@ -170,7 +170,17 @@ __global__ void __launch_bounds__(64) k_seed(DevIndex ix, MemOpt opt, TileView t
     Intv* mem = tv.intv;
     uint32_t n_ext = 0;
 
-#define QAT(p) (LDSQ ? (int)(sq[((p) >> 3) * 64] >> (((p) & 7) << 2) & 15u) : (int)qg[(p)])
+    // reads too long to stage in LDS (LDSQ = false) come from global memory: a lane walks its read one base at a time, forward
+    // then backward, so an aligned 8-byte window in registers answers seven of eight look-ups without a load
+    uint64_t qwin = 0;
+    const uint8_t* qwin_at = nullptr;
+    auto qat_g = [&](int p) -> int {
+        const uint8_t* a = qg + p;
+        const uint8_t* al = a - ((uintptr_t)a & 7);
+        if (al != qwin_at) { qwin_at = al; qwin = *(const uint64_t*)al; }
+        return (int)(qwin >> (((uintptr_t)a & 7) << 3) & 0xffu);
+    };
+#define QAT(p) (LDSQ ? (int)(sq[((p) >> 3) * 64] >> (((p) & 7) << 2) & 15u) : qat_g(p))
 #define FINISH() do { fin = true; st = S_IDLE; } while (0)       // the read's result is stored once, at the end of the iteration
 #define MEM_PUSH(X0, SZ, INFO) do { if (mem_n >= tv.intv_cap) ovf = true; else { Intv v_; v_.x0 = (X0); v_.x1 = 0; v_.size = (SZ); v_.info = (INFO); mem[mem_n++] = v_; } } while (0)
 #define PUSH_IK() do { if (V.push(nf, ik0, iks, end)) ++nf; else ovf = true; } while (0)
