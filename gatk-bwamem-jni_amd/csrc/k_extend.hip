@@ -265,7 +265,7 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
             h = h > f ? h : f;
             if (!act) h = -1;
             // row maximum with the last column that attains it: one scan over (h, column) keys; later chunks win ties
-            const int mk = wave_readlane(dpp_prefix_max(h << 8 | j, -1), 63);    // h = -1 outside the live columns: those keys are negative
+            const int mk = wave_readlane(dpp_prefix_max((int)((uint32_t)h << 8) | j, -1), 63);    // h = -1 outside the live columns: those keys are negative
             best = mk >= best ? mk : best;
             if (t + 1 < C) {
                 const int Plast = wave_readlane(P, 63);

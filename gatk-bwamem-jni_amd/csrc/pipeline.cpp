@@ -16,6 +16,7 @@
 #include <time.h>
 #include <sys/stat.h>
 #include <sys/mman.h>
+#include <dlfcn.h>
 #include <mutex>
 #include <condition_variable>
 #include <thread>
@@ -392,6 +393,26 @@ static void free_index(bwaidx_s* ix)
     if (ix->up_stream) { (void)hipStreamDestroy(ix->up_stream); ix->up_stream = nullptr; }
 }
 
+// ------------------------------------------------------------------------------------------ roctx ranges
+// Named ranges around the stages of a call (request upload, seeding chunk, each tile, tile download, pestat reduction) for
+// rocprofv3 --marker-trace.  The marker library is looked up at run time (rocprofiler-sdk's roctx, else roctracer's): no
+// link dependency, and without a profiler's library on the path the ranges are no-ops.
+struct Roctx {
+    int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+    Roctx() {
+        if (const char* e = getenv("BWAMEM_HIP_ROCTX")) if (atoi(e) == 0) return;
+        for (const char* lib : { "librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4" }) {
+            void* h = dlopen(lib, RTLD_LAZY | RTLD_LOCAL);
+            if (!h) continue;
+            push = (int (*)(const char*))dlsym(h, "roctxRangePushA"); pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+static Roctx& roctx() { static Roctx r; return r; }
+struct RoctxRange { bool on; RoctxRange(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); } ~RoctxRange() { if (on) roctx().pop(); } };
+
 // ------------------------------------------------------------------------------------------ timing
 static void timed_begin(Workspace& ws, KernelId id)
 {
@@ -647,6 +668,7 @@ static bool seed_chunk(bwaidx_s* ix, const MemOpt& opt, const SeedChunk& ch, See
         const int prio = e ? (atoi(e) > 0 ? hi : atoi(e) < 0 ? lo : 0) : hi;
         HIP_OK(hipStreamCreateWithPriority(&sw.stream, hipStreamNonBlocking, prio));
     }
+    RoctxRange rr("bwamem_hip:seed_chunk");
     const int T = (int)(ch.r1 - ch.r0), L = ch.L;
     const int max_groups = 8192;                                 // upper bound on the persistent k_seed grid
     const int groups = std::min(max_groups, (T + 63) / 64);
@@ -698,6 +720,7 @@ static TileView tile_view(const Workspace& ws, const TileSpec& spec, int64_t rea
 // buffer) or into the batch's device slab
 static bool emit_tile(Workspace& ws, bwamem_batch_s* b, size_t tile_index, const TileView& tv, int64_t out_total, TileOut& to)
 {
+    RoctxRange rr("bwamem_hip:tile_emit");
     OutSink& sink = b->sink;
     uint8_t* dst = nullptr;
     to.bytes = (size_t)out_total; to.d = nullptr; to.owned = false;
@@ -730,6 +753,7 @@ static bool emit_tile(Workspace& ws, bwamem_batch_s* b, size_t tile_index, const
 static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_batch_s* b, int64_t read_id0, size_t tile_index, const TileSpec& spec,
                         TileOut& to, const SeedStore& seeds_of_chunk, uint32_t chunk_r0, int& out_cap)
 {
+    RoctxRange rr("bwamem_hip:tile_se");
     const uint32_t r0 = spec.r0;
     const int T = (int)(spec.r1 - spec.r0), L = spec.L;
     int attempts = 0, job_cap_hint = 0;
@@ -922,6 +946,7 @@ static bool produce_streamed(bwaidx_s* ix, CallPipe& pp, bwamem_batch_s* b, cons
         uint64_t want = std::min<uint64_t>(chunk_reads, (uint64_t)max_T << std::min<size_t>(k, 8));
         want = std::min<uint64_t>(std::max<uint64_t>(want, even ? 2 : 1), b->n_reads - r);
         if (even && (want & 1) && r + want < b->n_reads) ++want;
+        RoctxRange rr("bwamem_hip:request_stretch");
         uint64_t got = 0;
         const char* end = scan_reads(p, want, max_bytes, &got);
         if (even && (got & 1) && r + got < b->n_reads) { uint64_t one = 0; end = scan_reads(end, 1, (size_t)-1, &one); got += one; }   // a pair is never split
@@ -1045,6 +1070,7 @@ struct PeTile { uint32_t r0 = 0; int T = 0, L = 0; uint8_t* seq = nullptr; const
 static bool pe_phase1_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_batch_s* b, int64_t read_id0, const TileSpec& spec, PeTile* pt,
                            const SeedStore& seeds_of_chunk, uint32_t chunk_r0, bool want_cand)
 {
+    RoctxRange rr("bwamem_hip:tile_pe_phase1");
     const uint32_t r0 = spec.r0;
     const int T = (int)(spec.r1 - spec.r0), L = spec.L;
     PE_REQ(ws.ensure_reads(opt, T, L, seeds_of_chunk.cap, ws.out_cap_hint, post_bytes_per_read(L, opt, false), false));
@@ -1100,6 +1126,7 @@ static bool pe_phase1_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
 
 static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_batch_s* b, int64_t read_id0, size_t tile_index, PeTile* pt, const MemPestat* pes, TileOut& to)
 {
+    RoctxRange rr("bwamem_hip:tile_pe_phase2");
     const int T = pt->T, L = pt->L;
     int attempts = 0, cap_u = 256, pe_job_cap = 0, pe_rescue_cap = 0;
     size_t pe_zpool = 0;
@@ -1264,6 +1291,7 @@ static bool align_batch_pe(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes
     if (pes0) return true;
     MemPestat pes[4];
     {
+        RoctxRange rr("bwamem_hip:pestat");
         std::vector<int8_t> cand_dir; std::vector<int64_t> cand_is;
         pe_candidates(b, cand_dir, cand_is);
         host_pestat(opt, cand_dir, cand_is, pes);
@@ -1589,6 +1617,7 @@ void* jnibwa_createAlignments(bwaidx_t* pIdx, mem_opt_t* pOpts, mem_pestat_t* pe
     // stretch by stretch (read offsets are found there), tiles are aligned as soon as their stretch is resident, and every
     // finished tile's records go straight into the malloc'ed block that is returned.
     void* res = 0;
+    RoctxRange rr("jnibwa_createAlignments");
     try {
         uint32_t n; memcpy(&n, pSeq, 4);
         bwamem_batch_s* b = new bwamem_batch_s();

@@ -28,7 +28,20 @@ void* dyn_smem() { return g_dyn.data(); }
 uint64_t* wave_slots() { return g_waves[g_cur->tid >> 6].slots; }
 uint64_t wave_alive_mask() { return g_waves[g_cur->tid >> 6].alive_mask; }
 
-static void yield() { Fiber* f = g_cur; swapcontext(&f->ctx, &g_sched); threadIdx.x = f->tid; }
+// AddressSanitizer must be told about every stack switch (it tracks the bounds of the running stack)
+#if defined(__SANITIZE_ADDRESS__)
+extern "C" void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
+static const void* g_sched_stack = nullptr; static size_t g_sched_size = 0;
+static void to_sched(Fiber* f, bool dying) { void* fake = nullptr; __sanitizer_start_switch_fiber(dying ? nullptr : &fake, g_sched_stack, g_sched_size); swapcontext(&f->ctx, &g_sched); __sanitizer_finish_switch_fiber(fake, nullptr, nullptr); }
+static void to_fiber(Fiber* f) { void* fake = nullptr; __sanitizer_start_switch_fiber(&fake, f->stack, STACK); swapcontext(&g_sched, &f->ctx); __sanitizer_finish_switch_fiber(fake, nullptr, nullptr); }
+static void fiber_entered() { __sanitizer_finish_switch_fiber(nullptr, &g_sched_stack, &g_sched_size); }
+#else
+static void to_sched(Fiber* f, bool) { swapcontext(&f->ctx, &g_sched); }
+static void to_fiber(Fiber* f) { swapcontext(&g_sched, &f->ctx); }
+static void fiber_entered() {}
+#endif
+static void yield() { Fiber* f = g_cur; to_sched(f, false); threadIdx.x = f->tid; }
 
 void sync_wave()
 {
@@ -58,6 +71,7 @@ void sync_block()
 
 static void trampoline()
 {
+    fiber_entered();
     (*g_body)();
     Fiber* f = g_cur;
     f->done = true;
@@ -67,7 +81,7 @@ static void trampoline()
     { const int row = (f->tid & 63) >> 4; const int ra = row_alive(w, row); if (ra > 0 && w.row_arrive[row] == ra) { w.row_arrive[row] = 0; ++w.row_gen[row]; } }
     --g_block_alive;
     if (g_block_alive > 0 && g_block_arrive == g_block_alive) { g_block_arrive = 0; ++g_block_gen; }
-    swapcontext(&f->ctx, &g_sched);
+    to_sched(f, true);
 }
 
 static std::mutex g_launch_mu;     // the fiber scheduler state is process-global: launches from several host threads are serialised
@@ -104,7 +118,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
                 Fiber& f = g_fibers[t];
                 if (f.done) continue;
                 g_cur = &f; threadIdx = dim3(t);
-                swapcontext(&g_sched, &f.ctx);
+                to_fiber(&f);
                 if (f.done) { --remaining; }
                 ++progressed;
             }

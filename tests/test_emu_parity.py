@@ -178,3 +178,19 @@ def test_stock_libbwa_hook(emu, oracle, rota_img, monkeypatch):
     monkeypatch.setenv("LIBBWA_PATH", "/nonexistent/libbwa.Linux.so")
     with pytest.raises(FileNotFoundError):
         B.stock_libbwa()
+
+
+def test_emu_sanitizers(oracle, rota_img, small_genome):
+    """AddressSanitizer + UBSan over the product's host code and kernel indexing (tests/emu `make asan`), in a child process
+    that preloads the sanitizer runtimes"""
+    import subprocess
+    import sys
+    B.make(os.path.join(B.ROOT, "tests", "emu"), "asan")
+    libs = [subprocess.run(["gcc", "-print-file-name=" + n], capture_output=True, text=True).stdout.strip() for n in ("libasan.so", "libubsan.so")]
+    if not all(os.path.isabs(x) and os.path.exists(x) for x in libs):
+        pytest.skip("no sanitizer runtimes next to this gcc")
+    seqs, img = small_genome
+    env = dict(os.environ, LD_PRELOAD=":".join(libs), ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0")
+    r = subprocess.run([sys.executable, os.path.join(B.ROOT, "tests", "emu", "sanitized_child.py"), rota_img, img, img[:-4]],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "sanitized-ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
