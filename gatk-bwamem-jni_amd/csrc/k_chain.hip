@@ -236,36 +236,46 @@ __global__ void __launch_bounds__(64, 8) k_chain(DevIndex ix, MemOpt opt, TileVi
     }
     if (n_chn > 0) {
         int i, k, n_kept = 0;
-        int32_t* kept_idx = (int32_t*)(tv.srt + s0);   // scratch: >= n_chn ints
+        // The kept chains, packed: {query begin, query end, weight | is_alt << 31, first shadowed chain} in 16 bytes each, in the
+        // B-tree's node pool (free since the traversal; 22 bytes per seed).  A read in a repeat family has hundreds of chains,
+        // every one of them kept, so this loop runs n^2 / 2 times for it: one independent 16-byte load per step instead of a
+        // chain -> first seed / last seed chase through three dependent loads.
+        int4* kept = (int4*)(((uintptr_t)bt.pool + 15) & ~(uintptr_t)15);
+        const int kept_cap = (int)(((size_t)bt.cap_nodes * BT_NODE_INTS * 4 - 16) / 16);
         ks_introsort((size_t)n_chn, a, ChainWLt());
+        if (n_chn > kept_cap) { atomicOr(tv.err, ERR_BTREE); return; }
         a[0].kept = 3;
-        kept_idx[n_kept++] = 0;
+        { int4 e0; e0.x = seeds[a[0].seed0].qbeg; e0.y = seeds[a[0].last].qbeg + seeds[a[0].last].len; e0.z = (int)((a[0].w & 0x7fffffffu) | (a[0].is_alt ? 0x80000000u : 0u)); e0.w = -1; kept[n_kept++] = e0; }
         for (i = 1; i < n_chn; ++i) {
             int large_ovlp = 0;
-            int bi = seeds[a[i].seed0].qbeg, ei = seeds[a[i].last].qbeg + seeds[a[i].last].len;
+            const Chain ci = a[i];
+            const int bi = seeds[ci.seed0].qbeg, ei = seeds[ci.last].qbeg + seeds[ci.last].len;
+            const int li = ei - bi, wi = (int)ci.w;
             for (k = 0; k < n_kept; ++k) {
-                int j = kept_idx[k];
-                int bj = seeds[a[j].seed0].qbeg, ej = seeds[a[j].last].qbeg + seeds[a[j].last].len;
+                const int4 kj = kept[k];
+                const int bj = kj.x, ej = kj.y, wj = kj.z & 0x7fffffff;
+                const bool j_alt = kj.z < 0;
                 int b_max = bj > bi ? bj : bi;
                 int e_min = ej < ei ? ej : ei;
-                if (e_min > b_max && (!a[j].is_alt || a[i].is_alt)) {
-                    int li = ei - bi, lj = ej - bj;
+                if (e_min > b_max && (!j_alt || ci.is_alt)) {
+                    int lj = ej - bj;
                     int min_l = li < lj ? li : lj;
                     if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level && min_l < opt.max_chain_gap) {
                         large_ovlp = 1;
-                        if (a[j].first < 0) a[j].first = i;
-                        if ((float)(int)a[i].w < (float)(int)a[j].w * opt.drop_ratio && (int)a[j].w - (int)a[i].w >= opt.min_seed_len << 1)
+                        if (kj.w < 0) ((int32_t*)&kept[k])[3] = i;
+                        if ((float)wi < (float)wj * opt.drop_ratio && wj - wi >= opt.min_seed_len << 1)
                             break;
                     }
                 }
             }
             if (k == n_kept) {
-                kept_idx[n_kept++] = i;
+                int4 e1; e1.x = bi; e1.y = ei; e1.z = (int)((ci.w & 0x7fffffffu) | (ci.is_alt ? 0x80000000u : 0u)); e1.w = -1;
+                kept[n_kept++] = e1;
                 a[i].kept = large_ovlp ? 2 : 3;
             }
         }
         for (i = 0; i < n_kept; ++i) {
-            int f = a[kept_idx[i]].first;
+            int f = kept[i].w;
             if (f >= 0) a[f].kept = 1;
         }
         for (i = k = 0; i < n_chn; ++i) {

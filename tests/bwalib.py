@@ -417,3 +417,20 @@ def reads_from_regions(seqs, regions, names, n, length=150, seed=1, **kw):
 def pairs_from_regions(seqs, regions, names, n_pairs, length=100, seed=1, **kw):
     sub = [(k, seqs[regions[k][0]][1][regions[k][1]:regions[k][2]]) for k in names]
     return simulate_pairs(sub, n_pairs, length=length, seed=seed, **kw)
+
+
+def synth_repeat_genome(total_bp=1500000, n_copies=1200, fam_len=300, div=0.10, seed=0xA1B):
+    """A genome with one SINE-like family: n_copies copies of a fam_len-base consensus at `div` divergence scattered over
+    i.i.d. sequence (both strands).  Reads drawn from the copies seed in hundreds of places (max_occ sampling, re-seeding,
+    frac_rep) and carry hundreds of chains into mem_chain_flt -- what a read in an Alu does on GRCh38.
+    -> (seqs, starts of the copies in contig 0)"""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=total_bp, dtype=np.uint8)
+    cons = rng.integers(0, 4, size=fam_len, dtype=np.uint8)
+    starts = np.sort(rng.choice(np.arange(1000, total_bp - fam_len - 1000, fam_len + 50), size=n_copies, replace=False))
+    for st in starts:
+        c = _diverge(rng, cons, div)
+        if rng.random() < 0.5:
+            c = (3 - c)[::-1]
+        g[st:st + fam_len] = c
+    return [("chrR", BASES[g].tobytes())], [int(x) for x in starts]

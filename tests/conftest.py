@@ -70,3 +70,11 @@ def alt_genome(hip_lib, workdir):
     _, img = _build_genome(hip_lib, workdir, "galt", 0, seqs=seqs, alt_names=alt_names)
     _, img0 = _build_genome(hip_lib, workdir, "galt_noalt", 0, seqs=seqs)
     return seqs, img, img0, alt_names, regions
+
+
+@pytest.fixture(scope="session")
+def repeat_genome(hip_lib, workdir):
+    """1.5 Mbp with a 300-base family in 1 200 diverged copies -> (seqs, img, copy starts)"""
+    seqs, starts = B.synth_repeat_genome()
+    _, img = _build_genome(hip_lib, workdir, "grep", 0, seqs=seqs)
+    return seqs, img, starts

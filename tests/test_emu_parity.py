@@ -194,3 +194,17 @@ def test_emu_sanitizers(oracle, rota_img, small_genome):
     r = subprocess.run([sys.executable, os.path.join(B.ROOT, "tests", "emu", "sanitized_child.py"), rota_img, img, img[:-4]],
                        env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "sanitized-ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_emu_repeat_family(emu, oracle, workdir):
+    """reads in a 150-copy family: more chains per read than a wavefront has lanes, all kept by mem_chain_flt"""
+    import ctypes
+    seqs, starts = B.synth_repeat_genome(total_bp=150000, n_copies=150, fam_len=200, div=0.06, seed=5)
+    fa = os.path.join(workdir, "grep_emu.fa")
+    B.write_fasta(fa, seqs)
+    build = emu.dll.jnibwa_createReferenceIndex
+    build.argtypes = [ctypes.c_char_p] * 3
+    assert build(fa.encode(), fa.encode(), b"auto") == 0 and emu.create_index_file(fa, fa + ".img") == 0
+    g = seqs[0][1]
+    reads = [bytes(g[st + 20:st + 170]) for st in starts[:3]] + [B.revcomp(bytes(g[starts[5] - 60:starts[5] + 90]))]
+    _cmp(emu, oracle, fa + ".img", reads)

@@ -469,3 +469,29 @@ def test_parity_long_reads_with_long_deletions(hip_lib, oracle, medium_genome, m
     assert sum(1 for r in dec for a in r if "190D" in a.get("cigar", "") or "150D" in a.get("cigar", "")) >= 6, "regions were not merged across the deletions"
     monkeypatch.setenv("BWAMEM_HIP_GCIGAR_RING", "256")
     assert _parity(hip_lib, oracle, img, reads) == got
+
+
+def test_parity_reads_in_a_repeat_family(hip_lib, oracle, repeat_genome):
+    """reads inside a 1 200-copy family: intervals of hundreds of occurrences (max_occ sampling, frac_rep), hundreds of chains
+    per read through mem_chain_flt's quadratic filter (k_chain's packed kept list), many extensions and XA candidates"""
+    seqs, img, starts = repeat_genome
+    g = seqs[0][1]
+    import random
+    rnd = random.Random(3)
+    reads = []
+    for st in rnd.sample(starts, 300):
+        off = rnd.randrange(-100, 250)                     # inside the copy, straddling its edge, or next to it
+        r = bytearray(g[st + off:st + off + 150])
+        for p in rnd.sample(range(150), rnd.randrange(0, 4)):
+            r[p] = ord("ACGT"[("ACGT".index(chr(r[p])) + 1) % 4])
+        reads.append(bytes(r) if rnd.random() < 0.5 else B.revcomp(bytes(r)))
+    reads += B.simulate_reads(seqs, 200, length=150, seed=9)
+    got = _parity(hip_lib, oracle, img, reads)
+    dec = B.decode_response(got, len(reads))
+    assert sum(1 for r in dec for a in r if a.get("xa")) > 20 and sum(1 for r in dec if r[0]["mapq"] == 0) > 50     # the family shows
+    _parity(hip_lib, oracle, img, reads[:150], max_occ=50, flag=B.MEM_F_ALL)
+    pairs = []
+    for st in rnd.sample(starts, 100):                     # one mate in a copy, the other in unique sequence next to it
+        a = st + rnd.randrange(-40, 120)
+        pairs += [bytes(g[a:a + 100]), B.revcomp(bytes(g[a + 250:a + 350]))]
+    _parity_pe(hip_lib, oracle, img, pairs)
