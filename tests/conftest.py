@@ -74,7 +74,7 @@ def alt_genome(hip_lib, workdir):
 
 @pytest.fixture(scope="session")
 def repeat_genome(hip_lib, workdir):
-    """1.5 Mbp with a 300-base family in 1 200 diverged copies -> (seqs, img, copy starts)"""
-    seqs, starts = B.synth_repeat_genome()
+    """1.5 Mbp with a young 300-base family: 600 copies at 2 % divergence -> (seqs, img, copy starts)"""
+    seqs, starts = B.synth_repeat_genome(n_copies=600, div=0.02)
     _, img = _build_genome(hip_lib, workdir, "grep", 0, seqs=seqs)
     return seqs, img, starts

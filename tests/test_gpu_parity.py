@@ -472,7 +472,7 @@ def test_parity_long_reads_with_long_deletions(hip_lib, oracle, medium_genome, m
 
 
 def test_parity_reads_in_a_repeat_family(hip_lib, oracle, repeat_genome):
-    """reads inside a 1 200-copy family: intervals of hundreds of occurrences (max_occ sampling, frac_rep), hundreds of chains
+    """reads inside a young 600-copy family: intervals of hundreds of occurrences (max_occ sampling, frac_rep), hundreds of chains
     per read through mem_chain_flt's quadratic filter (k_chain's packed kept list), many extensions and XA candidates"""
     seqs, img, starts = repeat_genome
     g = seqs[0][1]
@@ -488,7 +488,7 @@ def test_parity_reads_in_a_repeat_family(hip_lib, oracle, repeat_genome):
     reads += B.simulate_reads(seqs, 200, length=150, seed=9)
     got = _parity(hip_lib, oracle, img, reads)
     dec = B.decode_response(got, len(reads))
-    assert sum(1 for r in dec for a in r if a.get("xa")) > 20 and sum(1 for r in dec if r[0]["mapq"] == 0) > 50     # the family shows
+    assert sum(1 for r in dec for a in r if a.get("xa")) > 50 and sum(1 for r in dec if r[0]["mapq"] < 30) > 50     # the family shows
     _parity(hip_lib, oracle, img, reads[:150], max_occ=50, flag=B.MEM_F_ALL)
     pairs = []
     for st in rnd.sample(starts, 100):                     # one mate in a copy, the other in unique sequence next to it
