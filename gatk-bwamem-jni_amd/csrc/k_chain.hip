@@ -183,7 +183,6 @@ __global__ void __launch_bounds__(64, 8) k_chain(DevIndex ix, MemOpt opt, TileVi
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= tv.n_reads) return;
-    if (tv.order) r = tv.order[r];
     int64_t s0 = tv.seed_off[r], s1 = tv.seed_off[r + 1];
     int len = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
     Seed* seeds = tv.seeds;              // tile-global indices

@@ -17,9 +17,8 @@ template <bool WAVE_PER_READ>
 __global__ void __launch_bounds__(64, 6) k_post1(DevIndex ix, MemOpt opt, TileView tv, int ring)
 {
     HIP_DYNAMIC_SHARED(int32_t, smem)
-    int r = WAVE_PER_READ ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int r = WAVE_PER_READ ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (r >= tv.n_reads) return;
-    if (tv.order) r = tv.order[r];
     const bool writer = !WAVE_PER_READ || threadIdx.x == 0;
     WaveDp wd; wd.eh_h = smem; wd.eh_e = smem + ring; wd.tmpM = smem + 2 * ring; wd.rm = ring - 1; wd.lane = (int)threadIdx.x;
     PostScratch S = post_scratch_for(tv, r);
@@ -57,7 +56,6 @@ __global__ void __launch_bounds__(64, 6) k_final_prep(DevIndex ix, MemOpt opt, T
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= tv.n_reads) return;
-    if (tv.order) r = tv.order[r];
     AlnReg* a = tv.regs + tv.seed_off[r];
     const int n = tv.n_regs[r];
     int32_t* zbuf = (int32_t*)(tv.srt + tv.seed_off[r]);      // >= 2 ints per region
@@ -96,7 +94,6 @@ __global__ void __launch_bounds__(64, 6) k_final_se(DevIndex ix, MemOpt opt, Til
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= tv.n_reads) return;
-    if (tv.order) r = tv.order[r];
     PostScratch S = post_scratch_for(tv, r);
     const uint8_t* query = tv.seq + tv.seq_off[r];
     int l_query = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
