@@ -431,7 +431,9 @@ __global__ void __launch_bounds__(64, 2) k_gcigar_lane(DevIndex ix, MemOpt opt, 
 // HBM: as in k_extend -- rows of the general form in a slice of tv.dp_rows instead of LDS, a bounded grid walking the jobs
 // HBM = false: rows as rings of `ring` entries in LDS; a job whose band needs more than that is left for the HBM kernel
 // (launched after this one whenever the tile's reads are longer than the ring).
-template <bool HBM>
+// MAXCH: the widest register form compiled in (chunks of 64 diagonals).  Tiles of short reads use 2: the 13-chunk form needs over a
+// hundred registers, and the kernel's register count -- hence its occupancy -- is that of its hungriest path.
+template <bool HBM, int MAXCH>
 __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView tv, const DpJob* jobs, DpOut* outs, int n_jobs, uint32_t* cig_pool, int cig_cap,
                                                uint8_t* zpool, unsigned long long zpool_cap, unsigned long long* zpool_cur, int z_lds_cap, int ring,
                                                uint8_t* slabs, unsigned long long slab_bytes, int* queue)
@@ -499,12 +501,12 @@ __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView
             uint8_t* tile = z == z_lds || z_lds_cap < 4096 ? nullptr : z_lds;   // a matrix in global memory is walked through 64 x 64 tiles staged where the small ones live
             const bool diag_ok = l_end >= 0 && l_end <= 2 * w;
             const int nch = (2 * w + 1 + 63) >> 6;
-            if (!HBM && !(diag_ok && nch <= 13) && 2 * w + 4 > ring && l_query + 2 > ring) { deferred = true; break; }   // needs rows longer than the rings
+            if (!HBM && !(diag_ok && nch <= MAXCH) && 2 * w + 4 > ring && l_query + 2 > ring) { deferred = true; break; }   // needs rows longer than the rings
             if (diag_ok && nch <= 1) score = global_wave_diag(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
-            else if (diag_ok && nch <= 2) score = global_wave_diag_n<2>(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
-            else if (diag_ok && nch <= 4) score = global_wave_diag_n<4>(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
-            else if (diag_ok && nch <= 7) score = global_wave_diag_n<7>(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
-            else if (diag_ok && nch <= 13) score = global_wave_diag_n<13>(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
+            else if (MAXCH >= 2 && diag_ok && nch <= 2) score = global_wave_diag_n<2>(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
+            else if (MAXCH >= 4 && diag_ok && nch <= 4) score = global_wave_diag_n<4>(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
+            else if (MAXCH >= 7 && diag_ok && nch <= 7) score = global_wave_diag_n<7>(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
+            else if (MAXCH >= 13 && diag_ok && nch <= 13) score = global_wave_diag_n<13>(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
             else score = global_wave(ix, opt, L, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
             if (score == last_sc || w2 == opt.w << 2) break;
             last_sc = score;
@@ -540,7 +542,7 @@ void launch_gcigar(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const 
     int ring = 64;
     {   // the widest band bwa_gen_cigar2 can take here is 4 w + 3 (w2 <= opt.w << 2, and regions are only merged across gaps of up to 4 w)
         long long need = 8ll * (opt.w > 0 ? opt.w : 0) + 16;
-        if (need > (long long)cap + 2) need = (long long)cap + 2;
+        if (need > (long long)cap) need = (long long)cap;            // (rows as long as the read never wrap)
         if (need > 4096) need = 4096;                                // 48 KB of rows at most
         { const char* e = getenv("BWAMEM_HIP_GCIGAR_RING"); if (e && atoi(e) > 0 && atoi(e) < need) need = atoi(e); }   // (tests: force jobs over to the HBM kernel)
         if (slab_bytes) need = 64;                                   // long reads: the register forms cover bands of up to 832 columns; the rest goes to the HBM kernel
@@ -551,11 +553,13 @@ void launch_gcigar(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const 
     if (!tv.gcigar_hbm_only) {
         if (!slab_bytes) slabs = nullptr;
         const int grid = slabs ? gcigar_slab_grid(ix, n_jobs) : n_jobs;
-        hipLaunchKernelGGL(k_gcigar<false>, dim3(grid), dim3(64), 3 * (size_t)ring * sizeof(int32_t) + tail, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap, ring,
-                           slabs, (unsigned long long)slab_bytes, queue);
+        if (slabs) hipLaunchKernelGGL((k_gcigar<false, 13>), dim3(grid), dim3(64), 3 * (size_t)ring * sizeof(int32_t) + tail, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap, ring,
+                                      slabs, (unsigned long long)slab_bytes, queue);
+        else hipLaunchKernelGGL((k_gcigar<false, 2>), dim3(grid), dim3(64), 3 * (size_t)ring * sizeof(int32_t) + tail, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap, ring,
+                                (uint8_t*)nullptr, 0ull, queue);
     }
     if (tv.dp_rows) {
         const int grid = n_jobs < tv.dp_rows_blocks ? n_jobs : tv.dp_rows_blocks;
-        hipLaunchKernelGGL(k_gcigar<true>, dim3(grid), dim3(64), tail, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap, 0, (uint8_t*)nullptr, 0ull, (int*)nullptr);
+        hipLaunchKernelGGL((k_gcigar<true, 13>), dim3(grid), dim3(64), tail, st, ix, opt, tv, (const DpJob*)jobs, (DpOut*)outs, n_jobs, cig_pool, cig_cap, zpool, zpool_cap, zpool_cur, z_lds_cap, 0, (uint8_t*)nullptr, 0ull, (int*)nullptr);
     }
 }
