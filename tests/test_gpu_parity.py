@@ -495,3 +495,21 @@ def test_parity_reads_in_a_repeat_family(hip_lib, oracle, repeat_genome):
         a = st + rnd.randrange(-40, 120)
         pairs += [bytes(g[a:a + 100]), B.revcomp(bytes(g[a + 250:a + 350]))]
     _parity_pe(hip_lib, oracle, img, pairs)
+
+
+def test_bench_on_an_existing_image_with_a_stock_library_hook(small_genome, tmp_path):
+    """bench.py --image (BWAHIP_REF_IMG): an existing index image instead of the synthetic genome, reads sampled from its packed
+    reference; LIBBWA_PATH: the CPU baseline / checker taken from a library with the reference's jnibwa_* ABI.  No stock libbwa or
+    GATK image exists offline, so the hooks are pointed at this repo's own image and library: what is exercised is the plumbing."""
+    import subprocess
+    seqs, img = small_genome
+    env = dict(os.environ, LIBBWA_PATH=B.HIP_LIB)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_REHEARSAL"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(B.ROOT, "bench.py"), "--image", img, "--reads", "20000", "--steps", "1", "--warmup", "0",
+                        "--cpu-sample", "3000", "--cpu-reps", "1", "--h2h-calls", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["config"]["genome"] == "image" and out["config"]["genome_bp"] == sum(len(s) for _, s in seqs)
+    assert out["cpu_baseline"]["kind"] == "reference" and out["parity_sample"]["frac_identical_records"] == 1.0
+    assert out["host_to_host"]["identical_to_resident_response"] is True
