@@ -99,20 +99,20 @@ static __device__ ExtRes extend_wave(const DevIndex& ix, const MemOpt& opt, cons
             int e = act ? L.eh_e[j & RM] : 0;
             int t = M - oe_ins; t = t > 0 ? t : 0;
             int U = act ? t + j * e_ins : NEG_INF_I32;
-            int P = wave_prefix_max(U, lane);
-            int Pex = __shfl_up(P, 1);
+            int P = dpp_prefix_max(U, NEG_INF_I32);
+            int Pex = dpp_shr1(P, NEG_INF_I32);
             int f = fcarry - (j - c) * e_ins;
             if (lane > 0) { int g = Pex - (j - 1) * e_ins; f = f > g ? f : g; }
             int h = M > e ? M : e;
             h = h > f ? h : f;
             if (!act) h = -1;
-            int mc = wave_max(h);
+            int mc = wave_readlane(dpp_prefix_max(h, NEG_INF_I32), 63);
             unsigned long long bal = wave_ballot(act && h == mc);
             int mjc = c + 63 - __clzll(bal);
             if (mc >= m) { m = mc; mj = mjc; }
             int last = (end - 1 - c) < 63 ? (end - 1 - c) : 63;
-            hlast = wave_bcast(h, last);
-            int Plast = wave_bcast(P, 63);
+            hlast = wave_readlane(h, last);
+            int Plast = wave_readlane(P, 63);
             {   // F at column c+64 for the next chunk
                 int f1 = fcarry - WAVE * e_ins, f2 = Plast - (c + 63) * e_ins;
                 fcarry = f1 > f2 ? f1 : f2;
