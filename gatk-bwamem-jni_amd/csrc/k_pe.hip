@@ -643,12 +643,14 @@ void launch_sw_jobs(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const
     if (cap <= 0) return;
     (void)hipMemsetAsync(results, 0x81, pe_rescue_bytes(1, cap), st);
     // one instance per range of segment counts (the stripes are unrolled to the instance's maximum): up to 10 (150 bp mates),
-    // 11..16 (seed re-scoring windows of long reads: up to 199 bases in byte mode), 17..32 (250 bp mates in 16-bit mode)
+    // 11..16, 17..25 (seed re-scoring windows of long reads: up to 199 bases, 16-bit mode: 8 per segment), 26..32 (250 bp mates in 16-bit mode)
     hipLaunchKernelGGL((k_pe_rescue_sw<0, 10>), dim3((cap + 3) / 4), dim3(64), (size_t)4 * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b);
     if (max_qlen > 80)
         hipLaunchKernelGGL((k_pe_rescue_sw<10, 16>), dim3((cap + 3) / 4), dim3(64), (size_t)4 * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b);
     if (max_qlen > 128)
-        hipLaunchKernelGGL((k_pe_rescue_sw<16, 32>), dim3((cap + 3) / 4), dim3(64), (size_t)4 * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b);
+        hipLaunchKernelGGL((k_pe_rescue_sw<16, 25>), dim3((cap + 3) / 4), dim3(64), (size_t)4 * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b);
+    if (max_qlen > 200)
+        hipLaunchKernelGGL((k_pe_rescue_sw<25, 32>), dim3((cap + 3) / 4), dim3(64), (size_t)4 * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b);
 }
 size_t pe_rescue_bytes(int what, int cap) { return what == 0 ? (size_t)cap * sizeof(RescueJob) : (size_t)cap * sizeof(KswR); }
 void launch_pe_out(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, AlnReg* regs, const int64_t* reg_off,
