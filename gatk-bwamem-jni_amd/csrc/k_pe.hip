@@ -328,14 +328,15 @@ __global__ void k_pe_rescue_plan(DevIndex ix, MemOpt opt, TileView tv, PeView pv
 // mate rescue, step 2: ksw_align2 for the listed alignments, four per wavefront (one per 16-lane group, sw_common.h).
 // Instantiated for queries of up to 10 segments (150 bp mates) and up to 32 (250 bp mates in 16-bit mode); an instance
 // leaves the jobs outside (LO, NSEG] segments alone.
-template <int LO, int NSEG>
+template <int LO, int NSEG, int GW>
 __global__ void __launch_bounds__(64) k_pe_rescue_sw(DevIndex ix, MemOpt opt, TileView tv, const RescueJob* jobs, const int32_t* counter, int cap, KswR* results, int cap_b)
 {
     HIP_DYNAMIC_SHARED(uint64_t, blists)
+    constexpr int PER = 64 / GW;                                 // alignments per wavefront: 4 in byte mode (GW = 16), 8 in 16-bit mode (GW = 8)
     const int lane = threadIdx.x;
     const int n = *counter < cap ? *counter : cap;
-    if ((int)blockIdx.x * 4 >= n) return;
-    const int job = blockIdx.x * 4 + (lane >> 4);
+    if ((int)blockIdx.x * PER >= n) return;
+    const int job = blockIdx.x * PER + lane / GW;
     const bool on = job < n;
     RescueJob jb; jb.rb = 0; jb.read = 0; jb.tag = 0; jb.l_ms = 0; jb.is_rev = 0; jb.tlen = 0; jb.xtra = 0; jb.q_off = 0; jb.pad_ = 0;
     if (on) jb = jobs[job];
@@ -344,17 +345,11 @@ __global__ void __launch_bounds__(64) k_pe_rescue_sw(DevIndex ix, MemOpt opt, Ti
     const bool u8 = (jb.xtra & KSW_XBYTE) != 0;
     const int p = u8 ? 16 : 8;
     const int slen = (jb.l_ms + p - 1) / p;
-    const bool fits = on && slen > LO && slen <= NSEG;
+    const bool fits = on && u8 == (GW == 16) && slen > LO && slen <= NSEG;       // this instance's mode and range of segment counts
     if (__ballot(fits) == 0ull) return;
-    KswR res; res.score = RESCUE_NOT_RUN; res.te = res.qe = res.score2 = res.te2 = res.tb = res.qb = -1;
     int err = 0;
-    for (int mode = 1; mode <= 2; ++mode) {                     // byte-mode groups, then 16-bit-mode groups
-        const bool mine = fits && u8 == (mode == 1);
-        if (__ballot(mine) == 0ull) continue;
-        const KswR rr = sw_align2_wave4<NSEG>(ix, opt, I, mine, mode == 1 ? 1 : 2, jb.l_ms, jb.tlen, jb.xtra, L, lane, err);
-        if (mine) res = rr;
-    }
-    if (fits && (lane & 15) == 0) results[job] = res;
+    const KswR res = sw_align2_wave4<NSEG, GW>(ix, opt, I, fits, GW == 16 ? 1 : 2, jb.l_ms, jb.tlen, jb.xtra, L, lane, err);
+    if (fits && lane % GW == 0) results[job] = res;
     if (err) atomicOr(tv.err, err);
 }
 
@@ -642,15 +637,18 @@ void launch_sw_jobs(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const
 {
     if (cap <= 0) return;
     (void)hipMemsetAsync(results, 0x81, pe_rescue_bytes(1, cap), st);
-    // one instance per range of segment counts (the stripes are unrolled to the instance's maximum): up to 10 (150 bp mates),
-    // 11..16, 17..25 (seed re-scoring windows of long reads: up to 199 bases, 16-bit mode: 8 per segment), 26..32 (250 bp mates in 16-bit mode)
-    hipLaunchKernelGGL((k_pe_rescue_sw<0, 10>), dim3((cap + 3) / 4), dim3(64), (size_t)4 * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b);
-    if (max_qlen > 80)
-        hipLaunchKernelGGL((k_pe_rescue_sw<10, 16>), dim3((cap + 3) / 4), dim3(64), (size_t)4 * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b);
-    if (max_qlen > 128)
-        hipLaunchKernelGGL((k_pe_rescue_sw<16, 25>), dim3((cap + 3) / 4), dim3(64), (size_t)4 * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b);
-    if (max_qlen > 200)
-        hipLaunchKernelGGL((k_pe_rescue_sw<25, 32>), dim3((cap + 3) / 4), dim3(64), (size_t)4 * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b);
+    // one instance per mode and range of segment counts (the stripes are unrolled to the instance's maximum).  Byte mode
+    // (scores below 250: 150 bp mates), 16 bases per segment, four alignments per wave: up to 10, 11..16 segments.  16-bit mode
+    // (seed re-scoring windows of long reads, 250 bp mates), 8 bases per segment, eight alignments per wave: up to 10, 11..16,
+    // 17..25, 26..32 segments.
+#define SW_LAUNCH(LO, HI, GW) hipLaunchKernelGGL((k_pe_rescue_sw<LO, HI, GW>), dim3((cap + 64 / GW - 1) / (64 / GW)), dim3(64), (size_t)(64 / GW) * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b)
+    SW_LAUNCH(0, 10, 16);
+    if (max_qlen > 160) SW_LAUNCH(10, 16, 16);
+    SW_LAUNCH(0, 10, 8);
+    if (max_qlen > 80) SW_LAUNCH(10, 16, 8);
+    if (max_qlen > 128) SW_LAUNCH(16, 25, 8);
+    if (max_qlen > 200) SW_LAUNCH(25, 32, 8);
+#undef SW_LAUNCH
 }
 size_t pe_rescue_bytes(int what, int cap) { return what == 0 ? (size_t)cap * sizeof(RescueJob) : (size_t)cap * sizeof(KswR); }
 void launch_pe_out(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, AlnReg* regs, const int64_t* reg_off,

@@ -141,17 +141,19 @@ DEV KswR sw_align2(const DevIndex& ix, const MemOpt& opt, SwIn I, int qlen, int 
 // bytes or 8 shorts per vector) is lane k of a 16-lane group, the segment loop and the lazy-F loop are the sequential
 // dimension exactly as upstream has them, the H/E/Hmax stripes and the query profile live in registers (NSEG segments)
 // and only the row-maxima list is in LDS.
-struct SwLds { uint64_t* b; int cap_b; };               // [4][cap_b] row-maxima lists, one per 16-lane group
+struct SwLds { uint64_t* b; int cap_b; };               // [64 / GW][cap_b] row-maxima lists, one per group of GW lanes
 
-// Up to four alignments at once, one per 16-lane group of the wavefront (upstream's 16-byte vector is exactly one group; in
-// 16-bit mode the upper 8 lanes of a group idle).  A wave that owns several pairs in need of rescue would otherwise run their
+// Several alignments at once, one per group of GW lanes of the wavefront: GW = 16 for byte mode (upstream's 16-byte vector is
+// exactly one group: four alignments per wave), GW = 8 for 16-bit mode (eight shorts per vector: eight alignments per wave).  A wave that owns several pairs in need of rescue would otherwise run their
 // alignments one after another while every other wave has finished.  All arguments are per lane but uniform within a group;
 // `on` says whether the group has an alignment at all; `size` (byte or 16-bit mode) is the same for the whole wave.
-template <int NSEG>
+template <int NSEG, int GW>
 static __device__ __attribute__((noinline)) KswR sw_core_wave4(const DevIndex& ix, const MemOpt& opt, const SwIn& I, bool on, int size, int qlen, int tlen, int xtra, const SwLds& W, int lane, int& err)
 {
-    const int p = 8 * (3 - size), u8 = size == 1;
-    const int g = lane >> 4, sl = lane & 15;
+    static_assert(GW == 16 || GW == 8, "group width");
+    const int p = 8 * (3 - size), u8 = size == 1;              // (GW = 8 is for 16-bit mode only: p == GW)
+    const int g = lane / GW, sl = lane % GW;
+    const unsigned long long gmask = GW == 16 ? 0xffffull : 0xffull;
     const int slen = on ? (qlen + p - 1) / p : 0;
     const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
@@ -226,12 +228,12 @@ static __device__ __attribute__((noinline)) KswR sw_core_wave4(const DevIndex& i
                     else    { hh = subs_u16(hh, oe_ins); f = subs_u16(f, e_ins); more = f > hh; }
                 }
                 const unsigned long long bal = __ballot(la && act && more);
-                if (act && ((bal >> (g << 4)) & 0xffffull) == 0ull) done = true;
+                if (act && ((bal >> (g * GW)) & gmask) == 0ull) done = true;
             }
         }
         int imax = la && run ? mx : 0;
-        for (int o = 8; o > 0; o >>= 1) { const int u = __shfl_xor(imax, o); imax = imax > u ? imax : u; }
-        imax = __shfl(imax, g << 4);
+        for (int o = GW / 2; o > 0; o >>= 1) { const int u = __shfl_xor(imax, o); imax = imax > u ? imax : u; }
+        imax = __shfl(imax, g * GW);
         if (run && imax >= minsc) {
             if (n_b == 0 || (int32_t)bl[n_b - 1] + 1 != i) {
                 if (n_b >= W.cap_b) { err |= ERR_SCRATCH; stop = true; }
@@ -263,11 +265,11 @@ static __device__ __attribute__((noinline)) KswR sw_core_wave4(const DevIndex& i
                 if (v > best || (v == best && pos < bq)) { best = v; bq = pos; }
             }
         }
-        for (int o = 8; o > 0; o >>= 1) {
+        for (int o = GW / 2; o > 0; o >>= 1) {
             const int ub = __shfl_xor(best, o), uq = __shfl_xor(bq, o);
             if (ub > best || (ub == best && uq < bq)) { best = ub; bq = uq; }
         }
-        const int qe = __shfl(bq, g << 4);
+        const int qe = __shfl(bq, g * GW);
         if (on && (!u8 || r.score != 255)) {
             r.qe = qe;
             if (n_b > 0) {
@@ -284,16 +286,16 @@ static __device__ __attribute__((noinline)) KswR sw_core_wave4(const DevIndex& i
     return r;
 }
 
-// ksw_align2 for up to four alignments (see sw_core_wave4); arguments per lane, uniform within a 16-lane group
-template <int NSEG>
+// ksw_align2 for 64 / GW alignments (see sw_core_wave4); arguments per lane, uniform within a group of GW lanes
+template <int NSEG, int GW>
 DEV KswR sw_align2_wave4(const DevIndex& ix, const MemOpt& opt, SwIn I, bool on, int size, int qlen, int tlen, int xtra, const SwLds& W, int lane, int& err)
 {
     I.qrev = 0; I.trev = 0;
-    KswR r = sw_core_wave4<NSEG>(ix, opt, I, on, size, qlen, tlen, xtra, W, lane, err);
+    KswR r = sw_core_wave4<NSEG, GW>(ix, opt, I, on, size, qlen, tlen, xtra, W, lane, err);
     const bool again = on && !((xtra & KSW_XSTART) == 0 || ((xtra & KSW_XSUBO) && r.score < (xtra & 0xffff)));
     if (__ballot(again) == 0ull) return r;
     I.qrev = r.qe + 1; I.trev = r.te + 1;
-    KswR rr = sw_core_wave4<NSEG>(ix, opt, I, again, size, again ? r.qe + 1 : 0, tlen, KSW_XSTOP | r.score, W, lane, err);
+    KswR rr = sw_core_wave4<NSEG, GW>(ix, opt, I, again, size, again ? r.qe + 1 : 0, tlen, KSW_XSTOP | r.score, W, lane, err);
     if (again && r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
     return r;
 }
