@@ -491,20 +491,34 @@ static __device__ __forceinline__ void extend_read(const DevIndex& ix, const Mem
 
         for (int k = c.n - 1; k >= 0; --k) {
             const Seed s = seeds[(uint32_t)srt[k]];
-            int i;
-            for (i = 0; i < n_regs; ++i) {            // already covered by an earlier region?
-                const AlnReg p = regs[i];
-                int64_t rd; int qd, w, max_gap;
-                if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) continue;
-                if (s.len - p.seedlen0 > .1 * l_query) continue;
-                qd = s.qbeg - p.qb; rd = s.rbeg - p.rb;
-                max_gap = cal_max_gap(opt, qd < rd ? qd : (int)rd);
-                w = max_gap < p.w ? max_gap : p.w;
-                if (qd - rd < w && rd - qd < w) break;
-                qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
-                max_gap = cal_max_gap(opt, qd < rd ? qd : (int)rd);
-                w = max_gap < p.w ? max_gap : p.w;
-                if (qd - rd < w && rd - qd < w) break;
+            int i = n_regs;
+            // already covered by an earlier region?  Upstream walks the read's regions in order and stops at the first that
+            // contains the seed near its own diagonal; a read in a repeat family has hundreds of regions by now, so the lanes
+            // test 64 of them at a time and the first hit is the lowest set bit
+            for (int base = 0; base < n_regs; base += WAVE) {
+                const int ii = base + lane;
+                bool hit = false;
+                if (ii < n_regs) {
+                    const AlnReg* pp = regs + ii;
+                    const int64_t prb = pp->rb, pre = pp->re;
+                    const int pqb = pp->qb, pqe = pp->qe;
+                    if (!(s.rbeg < prb || s.rbeg + s.len > pre || s.qbeg < pqb || s.qbeg + s.len > pqe) && !(s.len - pp->seedlen0 > .1 * l_query)) {
+                        const int pw = pp->w;
+                        int64_t rd; int qd, w, max_gap;
+                        qd = s.qbeg - pqb; rd = s.rbeg - prb;
+                        max_gap = cal_max_gap(opt, qd < rd ? qd : (int)rd);
+                        w = max_gap < pw ? max_gap : pw;
+                        hit = qd - rd < w && rd - qd < w;
+                        if (!hit) {
+                            qd = pqe - (s.qbeg + s.len); rd = pre - (s.rbeg + s.len);
+                            max_gap = cal_max_gap(opt, qd < rd ? qd : (int)rd);
+                            w = max_gap < pw ? max_gap : pw;
+                            hit = qd - rd < w && rd - qd < w;
+                        }
+                    }
+                }
+                const unsigned long long bal = wave_ballot(hit);
+                if (bal) { i = base + __ffsll((long long)bal) - 1; break; }
             }
             if (i < n_regs) {
                 for (i = k + 1; i < c.n; ++i) {       // an overlapping off-diagonal seed forces extension
