@@ -13,7 +13,7 @@
 
 #define BT_T 5
 #define BT_MAXK (2 * BT_T - 1)
-#define BT_NODE_INTS 22     // is_internal, n, key[9], ptr[10], pad
+#define BT_NODE_INTS 40     // is_internal, n, key[9], ptr[10], pad, pos[9] (the keys' chain positions, 2 ints each: a comparison reads the node only)
 
 struct BTree {
     int32_t* pool; int n_nodes, cap_nodes, root, n_keys;
@@ -31,6 +31,7 @@ struct BTree {
 #define BT_N(x) ((x)[1])
 #define BT_KEY(x) ((x) + 2)
 #define BT_PTR(x) ((x) + 11)
+#define BT_POS(x) ((int64_t*)((x) + 22))
 
 DEV int bt_cmp_pos(int64_t a, int64_t b) { return (b < a) - (a < b); }
 
@@ -41,11 +42,11 @@ DEV int bt_getp_aux(const BTree& b, const int32_t* x, int64_t kpos, int* r)
     if (BT_N(x) == 0) return -1;
     while (begin < end) {
         int mid = (begin + end) >> 1;
-        if (bt_cmp_pos(b.cs[BT_KEY(x)[mid]].pos, kpos) < 0) begin = mid + 1;
+        if (bt_cmp_pos(BT_POS(x)[mid], kpos) < 0) begin = mid + 1;
         else end = mid;
     }
     if (begin == BT_N(x)) { *rr = 1; return BT_N(x) - 1; }
-    if ((*rr = bt_cmp_pos(kpos, b.cs[BT_KEY(x)[begin]].pos)) < 0) --begin;
+    if ((*rr = bt_cmp_pos(kpos, BT_POS(x)[begin])) < 0) --begin;
     return begin;
 }
 
@@ -70,13 +71,13 @@ DEV void bt_split(BTree& b, int xi, int i, int yi)
     if (b.ovf) return;
     int32_t *x = b.node(xi), *y = b.node(yi), *z = b.node(zi);
     BT_N(z) = BT_T - 1;
-    for (int j = 0; j < BT_T - 1; ++j) BT_KEY(z)[j] = BT_KEY(y)[j + BT_T];
+    for (int j = 0; j < BT_T - 1; ++j) { BT_KEY(z)[j] = BT_KEY(y)[j + BT_T]; BT_POS(z)[j] = BT_POS(y)[j + BT_T]; }
     if (y[0]) for (int j = 0; j < BT_T; ++j) BT_PTR(z)[j] = BT_PTR(y)[j + BT_T];
     BT_N(y) = BT_T - 1;
     for (int j = BT_N(x); j > i; --j) BT_PTR(x)[j + 1] = BT_PTR(x)[j];
     BT_PTR(x)[i + 1] = zi;
-    for (int j = BT_N(x) - 1; j >= i; --j) BT_KEY(x)[j + 1] = BT_KEY(x)[j];
-    BT_KEY(x)[i] = BT_KEY(y)[BT_T - 1];
+    for (int j = BT_N(x) - 1; j >= i; --j) { BT_KEY(x)[j + 1] = BT_KEY(x)[j]; BT_POS(x)[j + 1] = BT_POS(x)[j]; }
+    BT_KEY(x)[i] = BT_KEY(y)[BT_T - 1]; BT_POS(x)[i] = BT_POS(y)[BT_T - 1];
     ++BT_N(x);
 }
 
@@ -99,8 +100,8 @@ DEV void bt_put(BTree& b, int key)
         int32_t* x = b.node(xi);
         if (x[0] == 0) {
             int i = bt_getp_aux(b, x, kpos, 0);
-            for (int j = BT_N(x) - 1; j > i; --j) BT_KEY(x)[j + 1] = BT_KEY(x)[j];
-            BT_KEY(x)[i + 1] = key;
+            for (int j = BT_N(x) - 1; j > i; --j) { BT_KEY(x)[j + 1] = BT_KEY(x)[j]; BT_POS(x)[j + 1] = BT_POS(x)[j]; }
+            BT_KEY(x)[i + 1] = key; BT_POS(x)[i + 1] = kpos;
             ++BT_N(x);
             return;
         }
@@ -109,7 +110,7 @@ DEV void bt_put(BTree& b, int key)
             bt_split(b, xi, i, BT_PTR(x)[i]);
             if (b.ovf) return;
             x = b.node(xi);
-            if (bt_cmp_pos(kpos, b.cs[BT_KEY(x)[i]].pos) > 0) ++i;
+            if (bt_cmp_pos(kpos, BT_POS(x)[i]) > 0) ++i;
         }
         xi = BT_PTR(x)[i];
     }
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(64, 8) k_chain(DevIndex ix, MemOpt opt, TileVi
     if (n_chn > 0) {
         int i, k, n_kept = 0;
         // The kept chains, packed: {query begin, query end, weight | is_alt << 31, first shadowed chain} in 16 bytes each, in the
-        // B-tree's node pool (free since the traversal; 22 bytes per seed).  A read in a repeat family has hundreds of chains,
+        // B-tree's node pool (free since the traversal; 40 bytes per seed).  A read in a repeat family has hundreds of chains,
         // every one of them kept, so this loop runs n^2 / 2 times for it: one independent 16-byte load per step instead of a
         // chain -> first seed / last seed chase through three dependent loads.
         int4* kept = (int4*)(((uintptr_t)bt.pool + 15) & ~(uintptr_t)15);
