@@ -165,6 +165,8 @@ struct TileView {
     int32_t* dp_rows;             // null: DP rows of k_extend / k_gcigar in LDS; else dp_rows_blocks slices of 3 x (max_len + 2) ints (very long reads)
     int32_t dp_rows_blocks;
     int32_t debug;                // BWAMEM_HIP_DEBUGK: device-side progress prints (debugging aid)
+    const int32_t* order;         // [n_reads] or null: reads by falling seed count.  k_extend (one wavefront per read) takes read order[block]: the
+                                  // heaviest reads start first, so a tile's tail is no longer whichever heavy read happened to be dispatched last
     int32_t ext_hbm;              // k_extend keeps its rows in dp_rows (BWAMEM_HIP_DP_ROWS=hbm: tests)
     int32_t gcigar_hbm_only;      // k_gcigar: every wave-form job through the rows in dp_rows (same switch)
     int32_t pad_;

@@ -610,7 +610,7 @@ template <bool HBM>
 __global__ void __launch_bounds__(64, K_EXTEND_MIN_WAVES) k_extend(DevIndex ix, MemOpt opt, TileView tv)
 {
     HIP_DYNAMIC_SHARED(int32_t, smem)
-    if (!HBM) { extend_read<false>(ix, opt, tv, smem, blockIdx.x, threadIdx.x); return; }
+    if (!HBM) { extend_read<false>(ix, opt, tv, smem, tv.order ? tv.order[blockIdx.x] : (int)blockIdx.x, threadIdx.x); return; }
     for (int r = blockIdx.x; r < tv.n_reads; r += (int)gridDim.x) {
         extend_read<true>(ix, opt, tv, smem, r, threadIdx.x);
         __syncthreads();                                        // the next read reuses the rows and the staged query

@@ -483,6 +483,37 @@ __global__ void __launch_bounds__(256) k_scan_apply(const int32_t* in, int n, co
     for (int k = 0; k < 16; ++k) { if (i0 + k < n) out[i0 + k] = run; run += v[k]; }
 }
 
+// ---- reads by falling seed count (TileView::order): a counting sort over 32 logarithmic bins.  The order inside a bin is
+// whatever the atomics give: it decides which lane works on which read, never a result.
+DEV int order_bin(int n_seeds) { return n_seeds <= 0 ? 31 : __clz(n_seeds); }          // many seeds -> small bin -> early in the order
+__global__ void __launch_bounds__(256) k_order_count(const int32_t* n_seeds, int n, int32_t* bins)
+{
+    __shared__ int32_t h[32];
+    if (threadIdx.x < 32) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) atomicAdd(&h[order_bin(n_seeds[r])], 1);
+    __syncthreads();
+    if (threadIdx.x < 32 && h[threadIdx.x]) atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void k_order_offsets(int32_t* bins)                  // bins[0..32): counts -> bins[32..64): running cursors
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { int acc = 0; for (int b = 0; b < 32; ++b) { bins[32 + b] = acc; acc += bins[b]; } }
+}
+__global__ void __launch_bounds__(256) k_order_scatter(const int32_t* n_seeds, int n, int32_t* bins, int32_t* order)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) order[atomicAdd(&bins[32 + order_bin(n_seeds[r])], 1)] = r;
+}
+void launch_order(hipStream_t st, const int32_t* n_seeds, int n, int32_t* bins64, int32_t* order)
+{
+    if (n <= 0) return;
+    (void)hipMemsetAsync(bins64, 0, 64 * sizeof(int32_t), st);
+    hipLaunchKernelGGL(k_order_count, dim3((n + 255) / 256), dim3(256), 0, st, n_seeds, n, bins64);
+    hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(64), 0, st, bins64);
+    hipLaunchKernelGGL(k_order_scatter, dim3((n + 255) / 256), dim3(256), 0, st, n_seeds, n, bins64, order);
+}
+
 // ---- read offsets of a stretch of the request, found on the device (launch_nul_offsets)
 DEV uint32_t zero_byte_mask(uint32_t w) { return ~(((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w | 0x7f7f7f7fu); }   // 0x80 in every byte of w that is 0
 DEV void nul_words(const uint8_t* seq, int64_t n_bytes, int64_t b0, uint32_t m[4])

@@ -11,6 +11,7 @@ void launch_unpack_pac(hipStream_t st, const DevIndex& ix, int64_t start, int64_
 void launch_seed(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv);
 size_t scan_tmp_bytes(int64_t n);
 void launch_scan(hipStream_t st, const int32_t* in, int64_t* out, int n, int64_t* tmp);   // tmp: scan_tmp_bytes(n), or null (one-workgroup form)
+void launch_order(hipStream_t st, const int32_t* n_seeds, int n, int32_t* bins64, int32_t* order);   // TileView::order
 size_t nul_tmp_bytes(int64_t n_bytes);
 void launch_nul_offsets(hipStream_t st, const uint8_t* seq, int64_t n_bytes, int64_t* off, int64_t n_reads_max, int64_t* n_found, void* tmp);
 void launch_sa(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, int64_t n_occ);

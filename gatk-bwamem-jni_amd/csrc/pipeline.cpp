@@ -92,7 +92,7 @@ struct Workspace {
     int job_cap = 0, job_cig_cap = 0; size_t zpool_cap = 0;
     int out_cap_hint = 512;                           // bytes per read of the output staging slots (grown on overflow, kept across tiles)
     int dev_lds = 0;                                  // LDS per workgroup of the device this workspace lives on
-    DevBuf scan_tmp, packed;                          // block sums of the multi-block scan; the tile's packed records on their way to the host
+    DevBuf scan_tmp, packed, order;                        // block sums of the multi-block scan; the tile's packed records on their way to the host
     DevBuf pe_dir, pe_is, pe_caps, pe_reg_off2, pe_regs2, pe_ints2, pe_vpool, pe_scratch, pe_states, pe_rescue[3];   // paired-end stages
     hipStream_t stream = nullptr;
     std::vector<Timed> timed;
@@ -111,7 +111,7 @@ struct Workspace {
             dp_rows_blocks = (int)std::min<size_t>(4096, std::max<size_t>(256, ((size_t)2 << 30) / per_block));
             if (!dp_rows.ensure((size_t)dp_rows_blocks * per_block)) return false;
         }
-        return seed_off.ensure((t + 1) * 8) && scan_tmp.ensure(scan_tmp_bytes((int64_t)t + 1))
+        return seed_off.ensure((t + 1) * 8) && scan_tmp.ensure(scan_tmp_bytes((int64_t)t + 1)) && order.ensure(t * 4 + 64 * 4)
             && n_chains.ensure(t * 4) && n_regs.ensure(t * 4) && out.ensure(t * out_cap) && out_len.ensure(t * 4)
             && out_off.ensure((t + 1) * 8) && post.ensure(t * (size_t)post_per_read) && err.ensure(64) && cnt.ensure(sizeof(DevCounters));
     }
@@ -131,7 +131,7 @@ struct Workspace {
         DevBuf* all[] = { &intv, &n_intv, &smem, &l_rep, &n_seeds, &seed_off, &intv_seed_off, &seeds, &seed_rid, &cseeds, &chains,
                           &chain_store, &n_chains, &bt_nodes, &srt, &regs, &n_regs, &out, &out_len, &out_off, &post, &err, &cnt, &dp_rows,
                           &jobs, &job_out, &job_cig, &job_cnt, &zpool, &zslabs, &pe_dir, &pe_is, &pe_caps, &pe_reg_off2, &pe_regs2, &pe_ints2, &pe_vpool, &pe_scratch, &pe_states,
-                          &pe_rescue[0], &pe_rescue[1], &pe_rescue[2], &scan_tmp, &packed };
+                          &pe_rescue[0], &pe_rescue[1], &pe_rescue[2], &scan_tmp, &packed, &order };
         for (DevBuf* b : all) b->release();
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     }
@@ -148,6 +148,7 @@ struct Workspace {
         tv.err = err.as<int32_t>(); tv.cnt = cnt.as<DevCounters>();
         tv.dp_rows = dp_rows_blocks ? dp_rows.as<int32_t>() : nullptr; tv.dp_rows_blocks = dp_rows_blocks;
         tv.ext_hbm = ext_hbm; tv.gcigar_hbm_only = gcigar_hbm_only;
+        tv.order = nullptr;
         tv.job_cnt = job_cnt.as<int32_t>(); tv.jobs = jobs.p; tv.job_cap = job_cap;
         tv.smem_groups = (T + 63) / 64;
         { const char* e = getenv("BWAMEM_HIP_DEBUGK"); tv.debug = e ? atoi(e) : 0; }
@@ -719,6 +720,7 @@ static TileView tile_view(const Workspace& ws, const TileSpec& spec, int64_t rea
     v.n_seeds = seeds_of_chunk.n_seeds.as<int32_t>() + at;
     v.l_rep = seeds_of_chunk.l_rep.as<int32_t>() + at;
     v.smem_scratch = nullptr; v.smem_groups = 0;
+    { const char* e = getenv("BWAMEM_HIP_ORDER"); if (!(e && atoi(e) == 0)) v.order = ws.order.as<int32_t>() + 64; }   // filled by launch_order below the seed-count scan
     return v;
 }
 
@@ -781,6 +783,7 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
         HIP_OK(hipMemsetAsync(ws.cnt.p, 0, sizeof(DevCounters), ws.stream));
         HIP_OK(hipMemsetAsync(ws.job_cnt.p, 0, 64, ws.stream));
         TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_seeds, tv.seed_off, T, ws.scan_tmp.as<int64_t>()));
+        if (tv.order) TIMED(ws, K_OTHER, launch_order(ws.stream, tv.n_seeds, T, ws.order.as<int32_t>(), ws.order.as<int32_t>() + 64));
         int64_t n_occ = 0; int32_t err = 0; int32_t errv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIP_OK(hipMemcpyAsync(&n_occ, tv.seed_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
         HIP_OK(hipStreamSynchronize(ws.stream));
@@ -1087,6 +1090,7 @@ static bool pe_phase1_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
     PE_OK(hipMemsetAsync(ws.err.p, 0, 64, ws.stream));
     PE_OK(hipMemsetAsync(ws.cnt.p, 0, sizeof(DevCounters), ws.stream));
     TIMED(ws, K_OTHER, launch_scan(ws.stream, tv.n_seeds, tv.seed_off, T, ws.scan_tmp.as<int64_t>()));
+    if (tv.order) TIMED(ws, K_OTHER, launch_order(ws.stream, tv.n_seeds, T, ws.order.as<int32_t>(), ws.order.as<int32_t>() + 64));
     int64_t n_occ = 0; int32_t err = 0;
     PE_OK(hipMemcpyAsync(&n_occ, tv.seed_off + T, 8, hipMemcpyDeviceToHost, ws.stream));
     PE_OK(hipStreamSynchronize(ws.stream));

@@ -44,6 +44,7 @@ uint64_t wave_alive_mask();
 
 static inline int __popc(uint32_t x) { return __builtin_popcount(x); }
 static inline int __popcll(uint64_t x) { return __builtin_popcountll(x); }
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 
