@@ -501,9 +501,18 @@ __global__ void k_order_offsets(int32_t* bins)                  // bins[0..32): 
     if (threadIdx.x == 0 && blockIdx.x == 0) { int acc = 0; for (int b = 0; b < 32; ++b) { bins[32 + b] = acc; acc += bins[b]; } }
 }
 __global__ void __launch_bounds__(256) k_order_scatter(const int32_t* n_seeds, int n, int32_t* bins, int32_t* order)
-{
+{   // a block ranks its reads within each bin in LDS and reserves the bin's range with one global atomic: ten million reads of
+    // like weight would otherwise queue on a single cursor
+    __shared__ int32_t h[32], base[32];
+    if (threadIdx.x < 32) h[threadIdx.x] = 0;
+    __syncthreads();
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) order[atomicAdd(&bins[32 + order_bin(n_seeds[r])], 1)] = r;
+    int b = 0, rank = 0;
+    if (r < n) { b = order_bin(n_seeds[r]); rank = atomicAdd(&h[b], 1); }
+    __syncthreads();
+    if (threadIdx.x < 32) base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&bins[32 + threadIdx.x], h[threadIdx.x]) : 0;
+    __syncthreads();
+    if (r < n) order[base[b] + rank] = r;
 }
 void launch_order(hipStream_t st, const int32_t* n_seeds, int n, int32_t* bins64, int32_t* order)
 {
