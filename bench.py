@@ -335,17 +335,40 @@ def launch_ranks(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        # the contract is ONE JSON line on stdout: the ranks' stdout is captured and only rank 0's JSON line is passed on
+        # (communication libraries print banners there); stderr goes through untouched
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE, text=True))
+    import threading
+    outs = [""] * n
+
+    def drain(i):
+        outs[i] = procs[i].stdout.read()
+    th = [threading.Thread(target=drain, args=(i,), daemon=True) for i in range(n)]
+    for t in th:
+        t.start()
     rc = 0
+    while any(pr.poll() is None for pr in procs):              # a rank that dies leaves the others waiting in a barrier: end them
+        bad = [r for r, pr in enumerate(procs) if pr.poll() not in (None, 0)]
+        if bad:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+            break
+        time.sleep(0.2)
+    for t in th:
+        t.join(timeout=30)
     for r, pr in enumerate(procs):
         c = pr.wait()
         if c != 0:
             print("[bench] rank %d exited with code %d" % (r, c), file=sys.stderr, flush=True)
             rc = rc or c or 1
-    if rc:
-        for pr in procs:
-            if pr.poll() is None:
-                pr.kill()
+    if not rc:
+        lines = [l for l in outs[0].splitlines() if l.startswith("{")]
+        if len(lines) != 1:
+            print("[bench] rank 0 printed %d JSON lines" % len(lines), file=sys.stderr, flush=True)
+            rc = 1
+        else:
+            print(lines[0], flush=True)
     sys.exit(rc)
 
 
