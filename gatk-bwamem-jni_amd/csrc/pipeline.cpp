@@ -276,6 +276,12 @@ struct OutSink {
                 uint8_t* nb = (uint8_t*)realloc(h_buf, cap);
                 if (!nb) { aborted = true; cv.notify_all(); return false; }
                 h_buf = nb; h_cap = cap;
+#ifdef MADV_HUGEPAGE
+                {   // half a gigabyte of first-touch page faults sits on the workers' copy path: ask for huge pages (a hint; ignored where unavailable)
+                    const uintptr_t lo = ((uintptr_t)nb + 4095) & ~(uintptr_t)4095, hi = ((uintptr_t)nb + cap) & ~(uintptr_t)4095;
+                    if (hi > lo + ((size_t)2 << 20)) (void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);
+                }
+#endif
             }
         }
         ++inflight;
