@@ -272,7 +272,8 @@ struct OutSink {
             if (aborted) return false;
             if (need > h_cap) {
                 size_t est = reads_known ? (size_t)((double)placed_end / (double)reads_known * (double)reads_total * 1.25) : 0;
-                size_t cap = std::max(std::max(need, est), h_cap + h_cap / 2) + ((size_t)1 << 20);
+                const char* es = getenv("BWAMEM_HIP_OUT_SLACK");                  // (tests: 0 makes the block grow tile by tile)
+                size_t cap = std::max(std::max(need, est), h_cap + h_cap / 2) + (es ? (size_t)atoll(es) : (size_t)1 << 20);
                 uint8_t* nb = (uint8_t*)realloc(h_buf, cap);
                 if (!nb) { aborted = true; cv.notify_all(); return false; }
                 h_buf = nb; h_cap = cap;

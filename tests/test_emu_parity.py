@@ -208,3 +208,18 @@ def test_emu_repeat_family(emu, oracle, workdir):
     g = seqs[0][1]
     reads = [bytes(g[st + 20:st + 170]) for st in starts[:3]] + [B.revcomp(bytes(g[starts[5] - 60:starts[5] + 90]))]
     _cmp(emu, oracle, fa + ".img", reads)
+
+
+def test_emu_response_block_grows(emu, oracle, small_genome, monkeypatch):
+    """the response of jnibwa_createAlignments is sized from the first tiles' bytes per read; when later tiles need more, the
+    block is grown (realloc, only while no tile is copying into it) -- here the first tiles are unmappable reads with 8-byte
+    records and the later ones real reads, with no slack and several tiles in flight"""
+    import random
+    seqs, img = small_genome
+    rnd = random.Random(8)
+    junk = [bytes(rnd.choice(b"ACGT") for _ in range(60)) for _ in range(21)]
+    reads = junk + B.simulate_reads(seqs, 40, length=120, seed=12, sub=0.02, indel=0.004)
+    monkeypatch.setenv("BWAMEM_HIP_TILE", "7")
+    monkeypatch.setenv("BWAMEM_HIP_STREAMS", "3")
+    monkeypatch.setenv("BWAMEM_HIP_OUT_SLACK", "0")
+    _cmp(emu, oracle, img, reads)
