@@ -364,22 +364,15 @@ static __device__ inline int wave_prefix_sum(int v, int lane)
     for (int o = 1; o < WAVE; o <<= 1) { const int u = __shfl_up(v, o); if (lane >= o) v += u; }
     return v;
 }
-// band_d / band_pmin (optional): when the diagonal alone does not decide, the deficit and the smallest prefix score for
-// extend_band64 (band_d = -1: not eligible either)
 static __device__ bool extend_diag(const DevIndex& ix, const MemOpt& opt, const uint8_t* query, int lane,
-                                   int qlen, int q0, int qstep, int tlen, int64_t t0, int tstep, int zdrop, int h0, ExtRes& r,
-                                   int* band_d = nullptr, int* band_pmin = nullptr)
+                                   int qlen, int q0, int qstep, int tlen, int64_t t0, int tstep, int zdrop, int h0, ExtRes& r)
 {
-    if (band_d) *band_d = -1;
     if (tlen < qlen || qlen <= 0 || h0 <= 0) return false;
     const int mx = score_max(opt);
     const int oe_del = opt.o_del + opt.e_del, oe_ins = opt.o_ins + opt.e_ins;
     const int g1 = oe_del < oe_ins ? oe_del : oe_ins;
-    const int o_min = opt.o_del < opt.o_ins ? opt.o_del : opt.o_ins, e_min = opt.e_del < opt.e_ins ? opt.e_del : opt.e_ins;
-    const int d_lim = band_d ? o_min + 32 * e_min : g1;        // beyond this not even the 63-diagonal band is safe
     const ScoreTab ST = score_tab(opt);
-    int run = h0, max = h0, max_i = -1, deficit = 0, p_min = h0;
-    bool z_ok = true;
+    int run = h0, max = h0, max_i = -1, deficit = 0;
     for (int c = 0; c < qlen; c += WAVE) {
         const int j = c + lane;
         const bool act = j < qlen;
@@ -390,107 +383,17 @@ static __device__ bool extend_diag(const DevIndex& ix, const MemOpt& opt, const 
             s = score_at(p, n, ref_base2(ix, t0 + (int64_t)tstep * j));
         }
         deficit += wave_sum(act ? mx - s : 0);
-        if (deficit >= d_lim || deficit >= h0) return false;
+        if (deficit >= g1 || deficit >= h0) return false;
         const int P = run + wave_prefix_sum(s, lane);                 // P_j (lanes past the query repeat the last one)
         const int pm = wave_prefix_max(act ? P : NEG_INF_I32, lane);
         int before = __shfl_up(pm, 1);                                // the maximum before row j: h0, earlier chunks, earlier lanes
         if (lane == 0 || before < max) before = max;
-        if (zdrop > 0 && wave_any(act && P <= before && before - P > zdrop)) { if (!band_d) return false; z_ok = false; }
+        if (zdrop > 0 && wave_any(act && P <= before && before - P > zdrop)) return false;
         const int cm = wave_max(act ? P : NEG_INF_I32);
         if (cm > max) { max = cm; max_i = c + __ffsll((long long)wave_ballot(act && P == cm)) - 1; }
-        { const int lo = -wave_max(act ? -P : NEG_INF_I32); p_min = p_min < lo ? p_min : lo; }
         run = wave_bcast(P, WAVE - 1);
     }
-    if (deficit < g1 && z_ok) {
-        r.score = max; r.qle = max_i + 1; r.tle = max_i + 1; r.gtle = qlen; r.gscore = run; r.max_off = 0;
-        return true;
-    }
-    if (band_d) { *band_d = deficit; *band_pmin = p_min; }
-    return false;
-}
-
-// The same argument one step further, for queries of two or three 64-column chunks: with deficit D, any path that ever leaves
-// the band |j - i| <= K pays at least o + (K + 1) e in gaps (o, e the smaller open / extend penalties), so if D < o + (K + 1) e no
-// cell that depends on an out-of-band cell can be a row maximum, the best last-column cell, or tie with one, and
-// ksw_extend2's outputs are those of the DP restricted to the band -- cells outside dead -- computed here with upstream's
-// recurrence on ONE chunk of 64 diagonals (lane = diagonal: H stays in its lane from row to row, E comes from the lane to the
-// right), whatever the query length.  Upstream's window trimming never cuts a band cell while the row keeps a live tail
-// beyond the band, i.e. P_i > oe + (K + 1) e for both gap kinds (checked); its own band must cover ours or is used instead
-// (K clipped to w); rows past qlen + K cannot change an output; a loop stopped by z-drop before the diagonal reaches the last
-// column leaves the to-end score to upstream's far tails, and the form is refused (the DP below runs).
-static __device__ bool extend_band64(const DevIndex& ix, const MemOpt& opt, const uint8_t* query, const int lane,
-                                     int qlen, int q0, int qstep, int tlen, int64_t t0, int tstep,
-                                     int w, int end_bonus, int zdrop, int h0, int deficit, int p_min, unsigned long long& n_cells, ExtRes& r)
-{
-    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
-    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    if (qlen > 250 || tlen < qlen || h0 <= 0 || deficit < 0) return false;
-    const int mx = score_max(opt);
-    {   // upstream's band after clipping by the longest affordable gap
-        int max_ins = div_plus(qlen * mx + end_bonus - o_ins, e_ins, 1), max_del = div_plus(qlen * mx + end_bonus - o_del, e_del, 1);
-        max_ins = max_ins > 1 ? max_ins : 1; max_del = max_del > 1 ? max_del : 1;
-        w = w < max_ins ? w : max_ins; w = w < max_del ? w : max_del;
-    }
-    const int o_min = o_del < o_ins ? o_del : o_ins, e_min = e_del < e_ins ? e_del : e_ins;
-    int K = 0;
-    while (K < 32 && deficit >= o_min + (K + 1) * e_min) ++K;
-    K = K < w ? K : w;
-    if (K > 31) return false;
-    const int Kv = 31 < w ? 31 : w;                              // live diagonals: |d| <= Kv
-    {
-        int tail_min = oe_ins + (Kv + 1) * e_ins; const int t2 = oe_del + (Kv + 1) * e_del;
-        tail_min = (tail_min > t2 ? tail_min : t2) + 1;
-        if (p_min < tail_min) return false;
-    }
-    const ScoreTab ST = score_tab(opt);
-    const int d = lane - 32;                                     // the lane's diagonal: column j = i + d at row i
-    const bool dlive = d >= -Kv && d <= Kv;
-    int Hp, Ec = 0;                                              // eh[j].h = H(i-1, j-1) and eh[j].e = E(i, j) of the lane's cell
-    { const int j = d; int v = j == 0 ? h0 : j >= 1 && j <= qlen ? h0 - oe_ins - (j - 1) * e_ins : 0; Hp = v > 0 ? v : 0; }
-    int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
-    const int n_rows = tlen < qlen + Kv ? tlen : qlen + Kv;
-    const int le = lane * e_ins, lm1e = (lane - 1) * e_ins;
-    int tch = 4, i;
-    for (i = 0; i < n_rows; ++i) {
-        if ((i & 63) == 0) { const int ii = i + lane; tch = ii < tlen ? ref_base2(ix, t0 + (int64_t)tstep * ii) : 4; }
-        const int tb = wave_readlane(tch, i & 63);
-        const int j = i + d;
-        const bool inb = dlive && j >= 0 && j < qlen;
-        int sc = 0;
-        if (inb) { uint32_t p; int n; score_lane(ST, query[q0 + qstep * j], p, n); sc = score_at(p, n, tb); }
-        const int M = inb && Hp ? Hp + sc : 0;
-        const int E = inb ? Ec : 0;
-        int T = M - oe_ins; T = T > 0 ? T : 0;
-        const int U = inb ? T + le : NEG_INF_I32;
-        int F = dpp_shr1(dpp_prefix_max(U, NEG_INF_I32), NEG_INF_I32) - lm1e; F = F > 0 ? F : 0;
-        int h = M > E ? M : E; h = h > F ? h : F;
-        if (!inb) h = 0;
-        const int best = wave_readlane(dpp_prefix_max(inb ? (int)((uint32_t)h << 8) | j : -1, -1), 63);   // row maximum, last column attaining it
-        const int m = best < 0 ? 0 : best >> 8, mj = best < 0 ? -1 : best & 255;
-        if (best >= 0) n_cells += (unsigned long long)((i + Kv < qlen - 1 ? i + Kv : qlen - 1) - (i - Kv > 0 ? i - Kv : 0) + 1);
-        if (i >= qlen - 1 - Kv) {                                // the query's last column is in the band
-            const int hl = wave_readlane(dpp_prefix_max(inb && j == qlen - 1 ? h : -1, -1), 63);
-            if (hl >= 0) { max_ie = gscore > hl ? max_ie : i; gscore = gscore > hl ? gscore : hl; }
-        }
-        int t2 = M - oe_del; t2 = t2 > 0 ? t2 : 0;
-        int en = E - e_del; en = en > t2 ? en : t2;
-        Ec = dpp_shl1(inb ? en : 0, 0);                          // E(i+1, j) comes from the cell above = the lane to the right
-        { int h1i = h0 - (o_del + e_del * (i + 1)); h1i = h1i > 0 ? h1i : 0; Hp = j == -1 && dlive ? h1i : h; }   // the first-column value stands in for H(i, -1)
-        if (m == 0) break;
-        if (m > max) {
-            max = m; max_i = i; max_j = mj;
-            int df = mj - i; df = df < 0 ? -df : df;
-            max_off = max_off > df ? max_off : df;
-        } else if (zdrop > 0) {
-            if (i - max_i > mj - max_j) {
-                if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
-            } else {
-                if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
-            }
-        }
-    }
-    if (i < qlen - 1 && i < n_rows) return false;
-    r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+    r.score = max; r.qle = max_i + 1; r.tle = max_i + 1; r.gtle = qlen; r.gscore = run; r.max_off = 0;
     return true;
 }
 
@@ -499,13 +402,7 @@ static __device__ ExtRes extend_any(const DevIndex& ix, const MemOpt& opt, const
                                     int qlen, int q0, int qstep, int tlen, int64_t t0, int tstep,
                                     int w, int end_bonus, int zdrop, int h0, unsigned long long& n_cells, bool try_diag)
 {
-    if (try_diag) {
-        ExtRes r;
-        int bd = -1, bp = 0;
-        const bool wide = qlen + 1 > WAVE && qlen <= 250;          // two or three chunks per row in the column form: the band form pays one
-        if (extend_diag(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, zdrop, h0, r, wide ? &bd : nullptr, wide ? &bp : nullptr)) return r;
-        if (wide && bd >= 0 && extend_band64(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, bd, bp, n_cells, r)) return r;
-    }
+    { ExtRes r; if (try_diag && extend_diag(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, zdrop, h0, r)) return r; }
     if (qlen + 1 <= WAVE) return extend_wave_reg<1>(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
     if (qlen + 1 <= 2 * WAVE) return extend_wave_reg<2>(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
     if (qlen + 1 <= 3 * WAVE) return extend_wave_reg<3>(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
