@@ -10,6 +10,8 @@
 #include "dev_common.h"
 #include "kernels.h"
 #include "sw_common.h"
+#include "wave_ops.h"
+#include "chain_flt.h"
 
 #define BT_T 5
 #define BT_MAXK (2 * BT_T - 1)
@@ -180,21 +182,18 @@ DEV int chain_weight(const Chain& c, const Seed* seeds)
 
 struct ChainWLt { __device__ bool operator()(const Chain& a, const Chain& b) const { return a.w > b.w; } };
 
-__global__ void __launch_bounds__(64, 8) k_chain(DevIndex ix, MemOpt opt, TileView tv, Chain* chain_store)
+// chaining + chain weights + the weight sort of one read (one lane).  Returns the number of chains that enter mem_chain_flt's
+// overlap loop (sorted in a[]), 0 when the read has none.  kept: room for the packed kept chains, in the B-tree's node pool
+// (free since the traversal; 40 bytes per seed).
+DEV int chain_build(const DevIndex& ix, const MemOpt& opt, const TileView& tv, Chain* chain_store, int r, int64_t s0, int64_t s1, int64_t node0)
 {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= tv.n_reads) return;
-    int64_t s0 = tv.seed_off[r], s1 = tv.seed_off[r + 1];
     int len = (int)(tv.seq_off[r + 1] - tv.seq_off[r] - 1);
     Seed* seeds = tv.seeds;              // tile-global indices
     Chain* cs = chain_store + s0;        // creation order
     Chain* a = tv.chains + s0;           // B-tree order, then filtered
     int n_cs = 0;
-    tv.n_chains[r] = 0;
-    if (s1 == s0) return;
 
     BTree bt;
-    int64_t node0 = s0 / 4 + 3 * (int64_t)r;
     bt.pool = tv.bt_nodes + node0 * BT_NODE_INTS;
     bt.cap_nodes = (int)((s1 / 4 + 3 * (int64_t)(r + 1)) - node0);
     bt.n_nodes = 0; bt.n_keys = 0; bt.cs = cs; bt.ovf = false;
@@ -216,65 +215,63 @@ __global__ void __launch_bounds__(64, 8) k_chain(DevIndex ix, MemOpt opt, TileVi
             cs[n_cs] = c;
             bt_put(bt, n_cs);
             ++n_cs;
-            if (bt.ovf) { atomicOr(tv.err, ERR_BTREE); return; }
+            if (bt.ovf) { atomicOr(tv.err, ERR_BTREE); return 0; }
         }
     }
     int n_chn = bt_traverse(bt, a);
-    if (n_chn < 0) { atomicOr(tv.err, ERR_BTREE); return; }
+    if (n_chn < 0) { atomicOr(tv.err, ERR_BTREE); return 0; }
     float frac_rep = (float)tv.l_rep[r] / len;
     for (int i = 0; i < n_chn; ++i) a[i].frac_rep = frac_rep;
 
-    // ---- mem_chain_flt (row a9)
-    if (n_chn > 0) {
-        int i, k;
-        for (i = k = 0; i < n_chn; ++i) {
-            Chain c = a[i];
-            c.first = -1; c.kept = 0;
-            c.w = (uint32_t)chain_weight(c, seeds);
-            if ((int)c.w >= opt.min_chain_weight) a[k++] = c;
-        }
-        n_chn = k;
+    // ---- mem_chain_flt (row a9): weights, weight sort
+    int k = 0;
+    for (int i = 0; i < n_chn; ++i) {
+        Chain c = a[i];
+        c.first = -1; c.kept = 0;
+        c.w = (uint32_t)chain_weight(c, seeds);
+        if ((int)c.w >= opt.min_chain_weight) a[k++] = c;
     }
-    if (n_chn > 0) {
-        int i, k, n_kept = 0;
-        // The kept chains, packed: {query begin, query end, weight | is_alt << 31, first shadowed chain} in 16 bytes each, in the
-        // B-tree's node pool (free since the traversal; 40 bytes per seed).  A read in a repeat family has hundreds of chains,
-        // every one of them kept, so this loop runs n^2 / 2 times for it: one independent 16-byte load per step instead of a
-        // chain -> first seed / last seed chase through three dependent loads.
-        int4* kept = (int4*)(((uintptr_t)bt.pool + 15) & ~(uintptr_t)15);
-        const int kept_cap = (int)(((size_t)bt.cap_nodes * BT_NODE_INTS * 4 - 16) / 16);
-        ks_introsort((size_t)n_chn, a, ChainWLt());
-        if (n_chn > kept_cap) { atomicOr(tv.err, ERR_BTREE); return; }
-        a[0].kept = 3;
-        { int4 e0; e0.x = seeds[a[0].seed0].qbeg; e0.y = seeds[a[0].last].qbeg + seeds[a[0].last].len; e0.z = (int)((a[0].w & 0x7fffffffu) | (a[0].is_alt ? 0x80000000u : 0u)); e0.w = -1; kept[n_kept++] = e0; }
-        for (i = 1; i < n_chn; ++i) {
-            int large_ovlp = 0;
-            const Chain ci = a[i];
-            const int bi = seeds[ci.seed0].qbeg, ei = seeds[ci.last].qbeg + seeds[ci.last].len;
-            const int li = ei - bi, wi = (int)ci.w;
-            for (k = 0; k < n_kept; ++k) {
-                const int4 kj = kept[k];
-                const int bj = kj.x, ej = kj.y, wj = kj.z & 0x7fffffff;
-                const bool j_alt = kj.z < 0;
-                int b_max = bj > bi ? bj : bi;
-                int e_min = ej < ei ? ej : ei;
-                if (e_min > b_max && (!j_alt || ci.is_alt)) {
-                    int lj = ej - bj;
-                    int min_l = li < lj ? li : lj;
-                    if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level && min_l < opt.max_chain_gap) {
-                        large_ovlp = 1;
-                        if (kj.w < 0) ((int32_t*)&kept[k])[3] = i;
-                        if ((float)wi < (float)wj * opt.drop_ratio && wj - wi >= opt.min_seed_len << 1)
-                            break;
-                    }
-                }
-            }
-            if (k == n_kept) {
-                int4 e1; e1.x = bi; e1.y = ei; e1.z = (int)((ci.w & 0x7fffffffu) | (ci.is_alt ? 0x80000000u : 0u)); e1.w = -1;
-                kept[n_kept++] = e1;
-                a[i].kept = large_ovlp ? 2 : 3;
-            }
-        }
+    n_chn = k;
+    if (n_chn == 0) return 0;
+    const int kept_cap = (int)(((size_t)bt.cap_nodes * BT_NODE_INTS * 4 - 16) / 16);
+    ks_introsort((size_t)n_chn, a, ChainWLt());
+    if (n_chn > kept_cap) { atomicOr(tv.err, ERR_BTREE); return 0; }
+    return n_chn;
+}
+
+#define CHAIN_FLT_WAVE_MIN 48       // chains: from here on a read's overlap loop is run by the wavefront
+
+__global__ void __launch_bounds__(64, 8) k_chain(DevIndex ix, MemOpt opt, TileView tv, Chain* chain_store)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    Seed* seeds = tv.seeds;
+    int64_t s0 = 0, s1 = 0, node0 = 0;
+    int n_chn = 0, n_kept = 0;
+    if (r < tv.n_reads) {
+        tv.n_chains[r] = 0;
+        s0 = tv.seed_off[r]; s1 = tv.seed_off[r + 1];
+        node0 = s0 / 4 + 3 * (int64_t)r;
+        if (s1 > s0) n_chn = chain_build(ix, opt, tv, chain_store, r, s0, s1, node0);
+    }
+    Chain* a = tv.chains + s0;
+    int4* kept = (int4*)(((uintptr_t)(tv.bt_nodes + node0 * BT_NODE_INTS) + 15) & ~(uintptr_t)15);
+
+    // ---- mem_chain_flt's overlap loop: quadratic in the chains of a read, so reads with many chains get the wavefront, one
+    // after the other, and the rest a lane each
+    const bool by_wave = n_chn >= CHAIN_FLT_WAVE_MIN && !(tv.debug & 0x200);          // BWAMEM_HIP_DEBUGK=512: lane form only (tests)
+    if (n_chn > 0 && !by_wave) n_kept = chain_flt_lane(opt, seeds, a, n_chn, kept);
+    for (uint64_t heavy = __ballot(by_wave); heavy; heavy &= heavy - 1) {
+        const int src = __ffsll((long long)heavy) - 1;
+        const int64_t s0w = __shfl(s0, src), node0w = __shfl(node0, src);
+        const int nw = __shfl(n_chn, src);
+        const int got = chain_flt_wave(opt, seeds, tv.chains + s0w, nw, (int4*)(((uintptr_t)(tv.bt_nodes + node0w * BT_NODE_INTS) + 15) & ~(uintptr_t)15));
+        if (lane == src) n_kept = got;
+    }
+    if (n_chn == 0) return;
+
+    {
+        int i, k;
         for (i = 0; i < n_kept; ++i) {
             int f = kept[i].w;
             if (f >= 0) a[f].kept = 1;

@@ -448,39 +448,39 @@ __global__ void __launch_bounds__(256) k_scan_part(const int32_t* in, int n, int
     (void)block_excl_scan_256(sum, w4, tot);
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
-__global__ void __launch_bounds__(1024) k_scan_top(int64_t* part, int nb, int64_t* total_out)
-{   // in-place exclusive scan of the block sums (nb is small: n / 4096)
-    __shared__ int64_t wtot[16];
-    __shared__ int64_t carry_s;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    if (t == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < nb; base += 1024) {
-        const int i = base + t;
+__global__ void __launch_bounds__(64) k_scan_top(int64_t* part, int nb, int64_t* total_out)
+{   // in-place exclusive scan of many block sums (arrays beyond 2048 blocks): one wavefront, which finds a free
+    // slot next to other tiles' kernels where a 1024-thread workgroup waits for sixteen on one CU (measured: 4.5 ms per launch)
+    const int lane = threadIdx.x;
+    int64_t carry = 0;
+    for (int base = 0; base < nb; base += 64) {
+        const int i = base + lane;
         const int64_t v = i < nb ? part[i] : 0;
         int64_t incl = v;
         for (int o = 1; o < 64; o <<= 1) { int64_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
-        if (lane == 63) wtot[wv] = incl;
-        __syncthreads();
-        int64_t pre = carry_s, tot = 0;
-        for (int w = 0; w < 16; ++w) { const int64_t x = wtot[w]; if (w < wv) pre += x; tot += x; }
-        if (i < nb) part[i] = pre + incl - v;
-        __syncthreads();
-        if (t == 0) carry_s += tot;
-        __syncthreads();
+        if (i < nb) part[i] = carry + incl - v;
+        carry += __shfl(incl, 63);
     }
-    if (t == 0) *total_out = carry_s;
+    if (lane == 0) *total_out = carry;
 }
+template <bool FUSED>
 __global__ void __launch_bounds__(256) k_scan_apply(const int32_t* in, int n, const int64_t* part, int64_t* out)
-{
+{   // FUSED: part[] holds the block sums themselves and every block adds up the ones before it (no launch in between)
     __shared__ int64_t w4[4];
     const int i0 = blockIdx.x * 4096 + threadIdx.x * 16;
     int v[16];
     int64_t sum = 0;
     for (int k = 0; k < 16; ++k) { v[k] = i0 + k < n ? in[i0 + k] : 0; sum += v[k]; }
-    int64_t tot;
-    int64_t run = part[blockIdx.x] + block_excl_scan_256(sum, w4, tot);
+    int64_t tot, base;
+    if (FUSED) {
+        int64_t mine = 0, before;
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) mine += part[b];
+        (void)block_excl_scan_256(mine, w4, before);
+        base = before;
+    } else base = part[blockIdx.x];
+    int64_t run = base + block_excl_scan_256(sum, w4, tot);
     for (int k = 0; k < 16; ++k) { if (i0 + k < n) out[i0 + k] = run; run += v[k]; }
+    if (FUSED && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = base + tot;
 }
 
 // ---- reads by falling seed count (TileView::order): a counting sort over 32 logarithmic bins.  The order inside a bin is
@@ -691,15 +691,19 @@ void launch_seed(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const Ti
 }
 size_t scan_tmp_bytes(int64_t n) { return (size_t)((n + 4095) / 4096 + 2) * 8; }
 // exclusive scan int32 -> int64, out[n] = total.  Short arrays: the one-workgroup kernel.  Longer ones in three small
-// launches over 4096-element blocks (block sums, scan of the sums, block-local scan + offset), so that no stage of a tile
-// waits on one workgroup sharing its CU with other tiles' kernels.  tmp: scan_tmp_bytes(n) bytes.
+// launches over 4096-element blocks (block sums; beyond 2048 blocks a one-wave scan of the sums; block-local scan +
+// offset), so that no stage of a tile waits on one large workgroup finding room next to other tiles' kernels.
+// tmp: scan_tmp_bytes(n) bytes.
+static int scan_knob(const char* name, int dflt) { const char* e = getenv(name); return e && atoi(e) > 0 ? atoi(e) : dflt; }
 void launch_scan(hipStream_t st, const int32_t* in, int64_t* out, int n, int64_t* tmp)
 {
-    if (n <= 8192 || !tmp) { hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, in, out, n); return; }
+    const int single_max = scan_knob("BWAMEM_HIP_SCAN_SINGLE_MAX", 8192), fused_max = scan_knob("BWAMEM_HIP_SCAN_FUSED_MAX", 2048);   // test knobs
+    if (n <= single_max || !tmp) { hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, in, out, n); return; }
     const int nb = (n + 4095) / 4096;
     hipLaunchKernelGGL(k_scan_part, dim3(nb), dim3(256), 0, st, in, n, tmp);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, tmp, nb, out + n);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, in, n, (const int64_t*)tmp, out);
+    if (nb <= fused_max) { hipLaunchKernelGGL(k_scan_apply<true>, dim3(nb), dim3(256), 0, st, in, n, (const int64_t*)tmp, out); return; }
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, st, tmp, nb, out + n);
+    hipLaunchKernelGGL(k_scan_apply<false>, dim3(nb), dim3(256), 0, st, in, n, (const int64_t*)tmp, out);
 }
 size_t nul_tmp_bytes(int64_t n_bytes) { const size_t nb = (size_t)((n_bytes + 15) / 4096 + 2); return nb * 4 + 128 + (nb + 1) * 8 + scan_tmp_bytes((int64_t)nb); }
 // Offsets of the NUL-terminated reads of a stretch of the request (the job of the strlen walk at jnibwa.c:204-212, done

@@ -7,6 +7,7 @@
 #include <string.h>
 #include <vector>
 #include "../../gatk-bwamem-jni_amd/csrc/k_extend.hip"
+#include "../../gatk-bwamem-jni_amd/csrc/chain_flt.h"
 
 struct PairX { uint64_t x, y; };
 struct PairXLt { __device__ bool operator()(const PairX& a, const PairX& b) const { return a.x < b.x; } };
@@ -67,4 +68,40 @@ extern "C" int unit_extend(const uint8_t* query, int qlen, const uint8_t* target
     hipMemcpy(out6, d_out, 24, hipMemcpyDeviceToHost);
     hipFree(d_pac); hipFree(d_q); hipFree(d_out);
     return rc;
+}
+
+// mem_chain_flt's overlap loop in its two forms (k_chain.hip): wave != 0 -> chain_flt_wave by all 64 lanes, else chain_flt_lane on lane 0
+__global__ void __launch_bounds__(64) k_unit_chain_flt(MemOpt opt, const Seed* seeds, Chain* a, int n_chn, int4* kept, int wave, int* n_kept)
+{
+    int got = 0;
+    if (wave) got = chain_flt_wave(opt, seeds, a, n_chn, kept);
+    else if (threadIdx.x == 0) got = chain_flt_lane(opt, seeds, a, n_chn, kept);
+    if (threadIdx.x == 0) *n_kept = got;
+}
+
+// chains given as (query begin, query end, weight, is_alt), sorted by falling weight by the caller.
+// out_kept[i] = Chain::kept after the loop, out_first[k] = first shadowed chain of the k-th kept chain; returns n_kept
+extern "C" int unit_chain_flt(const MemOpt* opt, int n, const int32_t* qb, const int32_t* qe, const int32_t* w, const int32_t* alt, int wave, int32_t* out_kept, int32_t* out_first)
+{
+    std::vector<Seed> seeds((size_t)n); std::vector<Chain> a((size_t)n);
+    memset(seeds.data(), 0, seeds.size() * sizeof(Seed)); memset(a.data(), 0, a.size() * sizeof(Chain));
+    for (int i = 0; i < n; ++i) {
+        seeds[i].qbeg = qb[i]; seeds[i].len = qe[i] - qb[i]; seeds[i].next = -1;
+        a[i].seed0 = a[i].last = i; a[i].n = 1; a[i].w = (uint32_t)w[i]; a[i].is_alt = alt[i]; a[i].first = -1; a[i].kept = 0;
+    }
+    Seed* d_s; Chain* d_a; int4* d_k; int* d_n;
+    hipMalloc((void**)&d_s, (size_t)n * sizeof(Seed) + 16); hipMalloc((void**)&d_a, (size_t)n * sizeof(Chain) + 16);
+    hipMalloc((void**)&d_k, (size_t)n * 16 + 16); hipMalloc((void**)&d_n, 16);
+    hipMemcpy(d_s, seeds.data(), (size_t)n * sizeof(Seed), hipMemcpyHostToDevice);
+    hipMemcpy(d_a, a.data(), (size_t)n * sizeof(Chain), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_unit_chain_flt, dim3(1), dim3(64), 0, 0, *opt, (const Seed*)d_s, d_a, n, d_k, wave, d_n);
+    int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -1, n_kept = 0;
+    hipMemcpy(&n_kept, d_n, 4, hipMemcpyDeviceToHost);
+    hipMemcpy(a.data(), d_a, (size_t)n * sizeof(Chain), hipMemcpyDeviceToHost);
+    std::vector<int4> k((size_t)n);
+    hipMemcpy(k.data(), d_k, (size_t)n * 16, hipMemcpyDeviceToHost);
+    for (int i = 0; i < n; ++i) out_kept[i] = a[i].kept;
+    for (int i = 0; i < n_kept && i < n; ++i) out_first[i] = k[i].w;
+    hipFree(d_s); hipFree(d_a); hipFree(d_k); hipFree(d_n);
+    return rc ? rc : n_kept;
 }

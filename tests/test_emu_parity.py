@@ -196,8 +196,9 @@ def test_emu_sanitizers(oracle, rota_img, small_genome):
     assert r.returncode == 0 and "sanitized-ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
 
 
-def test_emu_repeat_family(emu, oracle, workdir):
-    """reads in a 150-copy family: more chains per read than a wavefront has lanes, all kept by mem_chain_flt"""
+def test_emu_repeat_family(emu, oracle, workdir, monkeypatch):
+    """reads in a 150-copy family: more chains per read than a wavefront has lanes, all kept by mem_chain_flt -- its overlap
+    loop run by the wavefront (k_chain.hip: chain_flt_wave) and, second pass, by the read's lane"""
     import ctypes
     seqs, starts = B.synth_repeat_genome(total_bp=150000, n_copies=150, fam_len=200, div=0.06, seed=5)
     fa = os.path.join(workdir, "grep_emu.fa")
@@ -208,6 +209,8 @@ def test_emu_repeat_family(emu, oracle, workdir):
     g = seqs[0][1]
     reads = [bytes(g[st + 20:st + 170]) for st in starts[:3]] + [B.revcomp(bytes(g[starts[5] - 60:starts[5] + 90]))]
     _cmp(emu, oracle, fa + ".img", reads)
+    monkeypatch.setenv("BWAMEM_HIP_DEBUGK", "512")
+    _cmp(emu, oracle, fa + ".img", reads[:2])
 
 
 def test_emu_response_block_grows(emu, oracle, small_genome, monkeypatch):
@@ -223,3 +226,25 @@ def test_emu_response_block_grows(emu, oracle, small_genome, monkeypatch):
     monkeypatch.setenv("BWAMEM_HIP_STREAMS", "3")
     monkeypatch.setenv("BWAMEM_HIP_OUT_SLACK", "0")
     _cmp(emu, oracle, img, reads)
+
+
+def test_emu_scan_forms(emu, monkeypatch):
+    """launch_scan (k_seed.hip): the one-workgroup form, the two-launch form whose blocks add up the block sums before them,
+    and the three-launch form with a one-wave scan of the sums must all be numpy's exclusive cumsum."""
+    import ctypes
+    import numpy as np
+    scan = emu.dll._Z11launch_scanPvPKiPliS2_
+    scan.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p]
+    scan.restype = None
+    rng = np.random.default_rng(5)
+    for single_max, fused_max, sizes in (("8192", "2048", (0, 1, 63, 4097)), ("1", "2048", (1, 4095, 4096, 3 * 4096 + 17)), ("1", "1", (4097, 70 * 4096 + 5))):
+        monkeypatch.setenv("BWAMEM_HIP_SCAN_SINGLE_MAX", single_max)
+        monkeypatch.setenv("BWAMEM_HIP_SCAN_FUSED_MAX", fused_max)
+        for n in sizes:
+            x = rng.integers(0, 1 << 20, size=max(n, 1), dtype=np.int32)[:n]
+            x[: n // 2] = rng.integers(0, 2 ** 31 - 1, size=n // 2, dtype=np.int32)       # totals beyond 32 bits
+            out = np.full(n + 1, -1, dtype=np.int64)
+            tmp = np.zeros(n // 4096 + 4, dtype=np.int64)
+            scan(None, x.ctypes.data, out.ctypes.data, n, tmp.ctypes.data)
+            want = np.concatenate([[0], np.cumsum(x.astype(np.int64))])
+            assert (out == want).all(), (single_max, fused_max, n)

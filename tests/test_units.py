@@ -112,3 +112,66 @@ def test_units_gpu_sort(oracle):
 @pytest.mark.gpu
 def test_units_gpu_extend(oracle):
     _check_extend(_load("hip"), oracle, 1500, 300)
+
+
+def _flt_reference(qb, qe, w, alt, mask_level, drop_ratio, max_chain_gap, min_seed_len):
+    """mem_chain_flt's overlap loop (upstream bwamem.c, the loop over the weight-sorted chains), restated in Python with C's
+    float comparisons -> (kept flag per chain, first shadowed chain per kept chain)"""
+    f32 = np.float32
+    n = len(qb)
+    kept = [0] * n; kept[0] = 3
+    chains = [0]; first = [-1]
+    for i in range(1, n):
+        large = 0
+        for idx, j in enumerate(chains):
+            b_max, e_min = max(qb[j], qb[i]), min(qe[j], qe[i])
+            if e_min > b_max and (not alt[j] or alt[i]):
+                min_l = min(qe[i] - qb[i], qe[j] - qb[j])
+                if f32(e_min - b_max) >= f32(min_l) * f32(mask_level) and min_l < max_chain_gap:
+                    large = 1
+                    if first[idx] < 0:
+                        first[idx] = i
+                    if f32(w[i]) < f32(w[j]) * f32(drop_ratio) and w[j] - w[i] >= min_seed_len << 1:
+                        break
+        else:
+            chains.append(i); first.append(-1)
+            kept[i] = 2 if large else 3
+    return kept, first
+
+
+def _check_chain_flt(units, oracle, n_cases, max_n):
+    units.unit_chain_flt.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 2
+    rng = np.random.default_rng(23)
+    for it in range(n_cases):
+        n = int(rng.integers(1, max_n))
+        L = int(rng.choice([150, 150, 250, 1000]))
+        style = it % 3
+        if style == 0:            # a repeat family: near-identical spans and weights, everything overlaps
+            qb = rng.integers(0, 12, size=n); qe = L - rng.integers(0, 12, size=n)
+            w = np.sort(rng.integers(L - 60, L - 20, size=n))[::-1]
+        elif style == 1:          # scattered short chains: few overlaps, nearly all kept
+            qb = rng.integers(0, L - 20, size=n); qe = np.minimum(qb + rng.integers(19, 60, size=n), L)
+            w = np.sort(rng.integers(19, 60, size=n))[::-1]
+        else:                     # a few dominant chains shadowing many weak ones
+            qb = rng.integers(0, L // 2, size=n); qe = np.minimum(qb + rng.integers(19, L, size=n), L)
+            w = np.sort(np.where(rng.random(n) < 0.1, rng.integers(100, 150, size=n), rng.integers(19, 70, size=n)))[::-1]
+        alt = (rng.random(n) < rng.choice([0.0, 0.0, 0.3])).astype(np.int32)
+        qb, qe, w = (np.ascontiguousarray(x, dtype=np.int32) for x in (qb, qe, w))
+        kw = dict(mask_level=float(rng.choice([0.5, 0.5, 0.2, 0.9])), drop_ratio=float(rng.choice([0.5, 0.5, 0.8])), max_chain_gap=int(rng.choice([10000, 10000, 100])))
+        opts = B.set_opt(bytearray(oracle.default_options()), **kw)
+        ob = ctypes.create_string_buffer(bytes(opts), 168)
+        want_kept, want_first = _flt_reference(qb.tolist(), qe.tolist(), w.tolist(), alt.tolist(), kw["mask_level"], kw["drop_ratio"], kw["max_chain_gap"], 19)
+        for wave in (0, 1):
+            got_kept = np.full(n, -9, dtype=np.int32); got_first = np.full(n, -9, dtype=np.int32)
+            nk = units.unit_chain_flt(ob, n, qb.ctypes.data, qe.ctypes.data, w.ctypes.data, alt.ctypes.data, wave, got_kept.ctypes.data, got_first.ctypes.data)
+            assert nk == len(want_first), (it, wave, n, nk, len(want_first))
+            assert got_kept.tolist() == want_kept and got_first[:nk].tolist() == want_first, (it, wave, n, kw)
+
+
+def test_units_emu_chain_flt(oracle):
+    _check_chain_flt(_load("emu"), oracle, 24, 200)
+
+
+@pytest.mark.gpu
+def test_units_gpu_chain_flt(oracle):
+    _check_chain_flt(_load("hip"), oracle, 300, 1500)
