@@ -15,7 +15,7 @@
 
 #define BT_T 5
 #define BT_MAXK (2 * BT_T - 1)
-#define BT_NODE_INTS 40     // is_internal, n, key[9], ptr[10], pad, pos[9] (the keys' chain positions, 2 ints each: a comparison reads the node only)
+// BT_NODE_INTS (bwamem_types.h) = 40: is_internal, n, key[9], ptr[10], pad, pos[9] (the keys' chain positions, 2 ints each: a comparison reads the node only)
 
 struct BTree {
     int32_t* pool; int n_nodes, cap_nodes, root, n_keys;

@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(64, 6) k_post1(DevIndex ix, MemOpt opt, TileVi
     if (tv.debug & 0xff) printf("[k] post1 read %d n=%d\n", r, tv.n_regs[r]);
     const int n_in = tv.n_regs[r];
     if (WAVE_PER_READ) __syncthreads();                              // every lane has read the count before lane 0 replaces it
-    int n = WAVE_PER_READ ? sort_dedup_patch_wave(ix, opt, S, query, n_in, a, wd) : sort_dedup_patch(ix, opt, S, query, n_in, a, tv.debug & 0xff);
+    SortKey* keys = (tv.debug & 0x400) ? nullptr : sort_keys_for(tv, r);          // BWAMEM_HIP_DEBUGK=1024: sort the regions themselves (tests)
+    int n = WAVE_PER_READ ? sort_dedup_patch_wave(ix, opt, S, query, n_in, a, wd, keys) : sort_dedup_patch(ix, opt, S, query, n_in, a, tv.debug & 0xff, keys);
     if (tv.debug & 0xff) printf("[k] post1 read %d done n=%d\n", r, n);
     if (writer)
         for (int i = 0; i < n; ++i)
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(64, 6) k_final_prep(DevIndex ix, MemOpt opt, T
     AlnReg* a = tv.regs + tv.seed_off[r];
     const int n = tv.n_regs[r];
     int32_t* zbuf = (int32_t*)(tv.srt + tv.seed_off[r]);      // >= 2 ints per region
-    mark_primary_se(opt, n, a, tv.read_id0 + r, zbuf);
+    mark_primary_se(opt, n, a, tv.read_id0 + r, zbuf, (tv.debug & 0x400) ? nullptr : sort_keys_for(tv, r));
     if (opt.flag & MEM_F_PRIMARY5) reorder_primary5(opt.T, n, a);
     int32_t *cnt = 0, *has_alt = 0;
     if (!(opt.flag & MEM_F_ALL) && n > 0) {

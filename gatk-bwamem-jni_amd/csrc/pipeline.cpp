@@ -124,7 +124,7 @@ struct Workspace {
         seed_cap = n;
         size_t s = (size_t)n + 16;
         return seeds.ensure(s * sizeof(Seed)) && seed_rid.ensure(s * 4) && cseeds.ensure(s * sizeof(Seed)) && chains.ensure(s * sizeof(Chain))
-            && chain_store.ensure(s * sizeof(Chain)) && bt_nodes.ensure((s / 4 + 3 * (size_t)T + 16) * 40 * 4) && srt.ensure(s * 8)
+            && chain_store.ensure(s * sizeof(Chain)) && bt_nodes.ensure((s / 4 + 3 * (size_t)T + 16) * BT_NODE_INTS * 4) && srt.ensure(s * 8)
             && regs.ensure(s * sizeof(AlnReg));
     }
     void release() {

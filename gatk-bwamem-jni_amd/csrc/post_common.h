@@ -452,6 +452,45 @@ DEV AlnRec reg2aln(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int l_
 struct RegReLt { __device__ bool operator()(const AlnReg& a, const AlnReg& b) const { return a.re < b.re; } };
 struct RegSLt  { __device__ bool operator()(const AlnReg& a, const AlnReg& b) const {
     return a.score > b.score || (a.score == b.score && (a.rb < b.rb || (a.rb == b.rb && a.qb < b.qb))); } };
+struct RegHLt  { __device__ bool operator()(const AlnReg& a, const AlnReg& b) const {
+    return a.score > b.score || (a.score == b.score && (a.is_alt < b.is_alt || (a.is_alt == b.is_alt && a.hash < b.hash))); } };
+struct RegHLt2 { __device__ bool operator()(const AlnReg& a, const AlnReg& b) const {
+    return a.is_alt < b.is_alt || (a.is_alt == b.is_alt && (a.score > b.score || (a.score == b.score && a.hash < b.hash))); } };
+
+// Sorting regions by key records.  A read in a repeat family carries hundreds of 96-byte regions and upstream sorts them four
+// times (introsort, unstable: the permutation of tied regions is part of the result).  ks_introsort decides by comparisons
+// only, so sorting 24-byte records {key, index} whose order is isomorphic to the comparator's gives the same permutation, and
+// the regions then move once each (cycle by cycle) instead of once per swap.  Human-like genome: k_post1 565 -> XXX ms,
+// k_final_prep's primary marking 346 -> XXX ms per 10 M reads.
+struct SortKey { uint64_t k0, k1; uint32_t k2; int32_t idx; };
+struct SortKeyLt { __device__ bool operator()(const SortKey& a, const SortKey& b) const {
+    return a.k0 < b.k0 || (a.k0 == b.k0 && (a.k1 < b.k1 || (a.k1 == b.k1 && a.k2 < b.k2))); } };
+DEV uint32_t key_asc(int32_t v) { return (uint32_t)v ^ 0x80000000u; }           // signed order -> unsigned order
+DEV uint32_t key_desc(int32_t v) { return ~((uint32_t)v ^ 0x80000000u); }
+DEV uint64_t key_asc64(int64_t v) { return (uint64_t)v ^ 0x8000000000000000ull; }
+DEV SortKey sort_key(const AlnReg& r, RegReLt) { SortKey k; k.k0 = key_asc64(r.re); k.k1 = 0; k.k2 = 0; k.idx = 0; return k; }
+DEV SortKey sort_key(const AlnReg& r, RegSLt)  { SortKey k; k.k0 = key_desc(r.score); k.k1 = key_asc64(r.rb); k.k2 = key_asc(r.qb); k.idx = 0; return k; }
+DEV SortKey sort_key(const AlnReg& r, RegHLt)  { SortKey k; k.k0 = (uint64_t)key_desc(r.score) << 32 | key_asc(r.is_alt); k.k1 = r.hash; k.k2 = 0; k.idx = 0; return k; }
+DEV SortKey sort_key(const AlnReg& r, RegHLt2) { SortKey k; k.k0 = (uint64_t)key_asc(r.is_alt) << 32 | key_desc(r.score); k.k1 = r.hash; k.k2 = 0; k.idx = 0; return k; }
+#define SORT_BY_KEY_MIN 12
+// room for a read's key records: its share of the chaining B-tree's node pool (40 bytes per seed + 480; free once k_chain is done)
+DEV SortKey* sort_keys_for(const TileView& tv, int r) { return (SortKey*)(tv.bt_nodes + (tv.seed_off[r] / 4 + 3 * (int64_t)r) * BT_NODE_INTS); }
+
+template <typename LT>
+DEV void sort_regs(int n, AlnReg* a, SortKey* keys, LT lt)
+{
+    if (!keys || n < SORT_BY_KEY_MIN) { ks_introsort((size_t)n, a, lt); return; }
+    for (int i = 0; i < n; ++i) { SortKey k = sort_key(a[i], lt); k.idx = i; keys[i] = k; }
+    ks_introsort((size_t)n, keys, SortKeyLt());
+    for (int i = 0; i < n; ++i) {                      // a[i] <- a[keys[i].idx], one cycle of the permutation at a time
+        int src = keys[i].idx;
+        if (src == i) continue;
+        const AlnReg first = a[i];
+        int j = i;
+        while (src != i) { a[j] = a[src]; keys[j].idx = j; j = src; src = keys[j].idx; }
+        a[j] = first; keys[j].idx = j;
+    }
+}
 
 // mem_patch_reg: can two colinear regions be merged into one global alignment?
 DEV int patch_reg(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const uint8_t* query, const AlnReg& a, const AlnReg& b, int* _w, const WaveDp* wd = nullptr)
@@ -477,13 +516,12 @@ DEV int patch_reg(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const u
 }
 
 // mem_sort_dedup_patch; query == 0 disables patching (the mate-rescue caller)
-DEV int sort_dedup_patch(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const uint8_t* query, int n, AlnReg* a, int dbg = 0)
+DEV int sort_dedup_patch(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const uint8_t* query, int n, AlnReg* a, int dbg = 0, SortKey* keys = nullptr)
 {
     int m, i, j;
     if (n <= 1) return n;
-    if (dbg) printf("[k] sdp: n=%d before sort1\n", n);
-    ks_introsort((size_t)n, a, RegReLt());
-    if (dbg) printf("[k] sdp: after sort1: re %lld %lld\n", (long long)a[0].re, (long long)a[1].re);
+    if (dbg & 0xff) printf("[k] sdp: n=%d before sort1\n", n);
+    sort_regs(n, a, keys, RegReLt());
     for (i = 0; i < n; ++i) a[i].n_comp = 1;
     for (i = 1; i < n; ++i) {
         AlnReg* p = &a[i];
@@ -515,9 +553,7 @@ DEV int sort_dedup_patch(const DevIndex& ix, const MemOpt& opt, PostScratch& S, 
     for (i = 0, m = 0; i < n; ++i)
         if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
     n = m;
-    if (dbg) printf("[k] sdp: before sort2 n=%d\n", n);
-    ks_introsort((size_t)n, a, RegSLt());
-    if (dbg) printf("[k] sdp: after sort2\n");
+    sort_regs(n, a, keys, RegSLt());
     for (i = 1; i < n; ++i)
         if (a[i].score == a[i - 1].score && a[i].rb == a[i - 1].rb && a[i].qb == a[i - 1].qb)
             a[i].qe = a[i].qb;
@@ -530,13 +566,13 @@ DEV int sort_dedup_patch(const DevIndex& ix, const MemOpt& opt, PostScratch& S, 
 // The same procedure run by a whole wavefront on one read (k_post1<true>, long reads): every lane follows the control flow
 // (all decisions are read from memory that only lane 0 writes, with a barrier on either side of each write), lane 0 does the
 // updates, and the patch alignments run across the lanes.
-DEV int sort_dedup_patch_wave(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const uint8_t* query, int n, AlnReg* a, const WaveDp& wd)
+DEV int sort_dedup_patch_wave(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const uint8_t* query, int n, AlnReg* a, const WaveDp& wd, SortKey* keys = nullptr)
 {
     const bool w0 = wd.lane == 0;
     int m = n, i, j;
     if (n <= 1) return n;
     __syncthreads();
-    if (w0) { ks_introsort((size_t)n, a, RegReLt()); for (i = 0; i < n; ++i) a[i].n_comp = 1; }
+    if (w0) { sort_regs(n, a, keys, RegReLt()); for (i = 0; i < n; ++i) a[i].n_comp = 1; }
     __syncthreads();
     for (i = 1; i < n; ++i) {
         AlnReg* p = &a[i];
@@ -577,7 +613,7 @@ DEV int sort_dedup_patch_wave(const DevIndex& ix, const MemOpt& opt, PostScratch
         for (i = 0, m = 0; i < n; ++i)
             if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
         n = m;
-        ks_introsort((size_t)n, a, RegSLt());
+        sort_regs(n, a, keys, RegSLt());
         for (i = 1; i < n; ++i)
             if (a[i].score == a[i - 1].score && a[i].rb == a[i - 1].rb && a[i].qb == a[i - 1].qb)
                 a[i].qe = a[i].qb;
@@ -590,11 +626,6 @@ DEV int sort_dedup_patch_wave(const DevIndex& ix, const MemOpt& opt, PostScratch
 }
 
 // ------------------------------------------------------------------ primary marking (a14)
-struct RegHLt  { __device__ bool operator()(const AlnReg& a, const AlnReg& b) const {
-    return a.score > b.score || (a.score == b.score && (a.is_alt < b.is_alt || (a.is_alt == b.is_alt && a.hash < b.hash))); } };
-struct RegHLt2 { __device__ bool operator()(const AlnReg& a, const AlnReg& b) const {
-    return a.is_alt < b.is_alt || (a.is_alt == b.is_alt && (a.score > b.score || (a.score == b.score && a.hash < b.hash))); } };
-
 DEV void mark_primary_core(const MemOpt& opt, int n, AlnReg* a, int32_t* z)
 {
     int i, k, nz = 0, tmp;
@@ -621,7 +652,7 @@ DEV void mark_primary_core(const MemOpt& opt, int n, AlnReg* a, int32_t* z)
     }
 }
 
-DEV int mark_primary_se(const MemOpt& opt, int n, AlnReg* a, int64_t id, int32_t* z)
+DEV int mark_primary_se(const MemOpt& opt, int n, AlnReg* a, int64_t id, int32_t* z, SortKey* keys = nullptr)
 {
     int i, n_pri;
     if (n == 0) return 0;
@@ -629,7 +660,7 @@ DEV int mark_primary_se(const MemOpt& opt, int n, AlnReg* a, int64_t id, int32_t
         a[i].sub = a[i].alt_sc = 0; a[i].secondary = a[i].secondary_all = -1; a[i].hash = hash_64((uint64_t)(id + i));
         if (!a[i].is_alt) ++n_pri;
     }
-    ks_introsort((size_t)n, a, RegHLt());
+    sort_regs(n, a, keys, RegHLt());
     mark_primary_core(opt, n, a, z);
     for (i = 0; i < n; ++i) {
         AlnReg* p = &a[i];
@@ -637,7 +668,7 @@ DEV int mark_primary_se(const MemOpt& opt, int n, AlnReg* a, int64_t id, int32_t
         if (!p->is_alt && p->secondary >= 0 && a[p->secondary].is_alt) p->alt_sc = a[p->secondary].score;
     }
     if (n_pri >= 0 && n_pri < n) {
-        if (n_pri > 0) ks_introsort((size_t)n, a, RegHLt2());
+        if (n_pri > 0) sort_regs(n, a, keys, RegHLt2());
         for (i = 0; i < n; ++i) z[a[i].secondary_all] = i;
         for (i = 0; i < n; ++i) {
             if (a[i].secondary >= 0) {

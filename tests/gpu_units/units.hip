@@ -8,6 +8,7 @@
 #include <vector>
 #include "../../gatk-bwamem-jni_amd/csrc/k_extend.hip"
 #include "../../gatk-bwamem-jni_amd/csrc/chain_flt.h"
+#include "../../gatk-bwamem-jni_amd/csrc/post_common.h"
 
 struct PairX { uint64_t x, y; };
 struct PairXLt { __device__ bool operator()(const PairX& a, const PairX& b) const { return a.x < b.x; } };
@@ -104,4 +105,26 @@ extern "C" int unit_chain_flt(const MemOpt* opt, int n, const int32_t* qb, const
     for (int i = 0; i < n_kept && i < n; ++i) out_first[i] = k[i].w;
     hipFree(d_s); hipFree(d_a); hipFree(d_k); hipFree(d_n);
     return rc ? rc : n_kept;
+}
+
+// sort_regs (post_common.h): the four region sorts, on the regions themselves (by_key == 0) or through key records
+__global__ void k_unit_sort_regs(AlnReg* a, int n, int which, SortKey* keys)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    if (which == 0) sort_regs(n, a, keys, RegReLt());
+    else if (which == 1) sort_regs(n, a, keys, RegSLt());
+    else if (which == 2) sort_regs(n, a, keys, RegHLt());
+    else sort_regs(n, a, keys, RegHLt2());
+}
+extern "C" int unit_sizeof_alnreg() { return (int)sizeof(AlnReg); }
+extern "C" int unit_sort_regs(int n, void* regs, int which, int by_key)
+{
+    AlnReg* d; SortKey* k;
+    hipMalloc((void**)&d, (size_t)n * sizeof(AlnReg) + 16); hipMalloc((void**)&k, (size_t)n * sizeof(SortKey) + 16);
+    hipMemcpy(d, regs, (size_t)n * sizeof(AlnReg), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_unit_sort_regs, dim3(1), dim3(64), 0, 0, d, n, which, by_key ? k : (SortKey*)0);
+    int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+    hipMemcpy(regs, d, (size_t)n * sizeof(AlnReg), hipMemcpyDeviceToHost);
+    hipFree(d); hipFree(k);
+    return rc;
 }

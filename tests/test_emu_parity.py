@@ -209,7 +209,7 @@ def test_emu_repeat_family(emu, oracle, workdir, monkeypatch):
     g = seqs[0][1]
     reads = [bytes(g[st + 20:st + 170]) for st in starts[:3]] + [B.revcomp(bytes(g[starts[5] - 60:starts[5] + 90]))]
     _cmp(emu, oracle, fa + ".img", reads)
-    monkeypatch.setenv("BWAMEM_HIP_DEBUGK", "512")
+    monkeypatch.setenv("BWAMEM_HIP_DEBUGK", "1536")            # 512: the overlap loop by lane; 1024: regions sorted in place
     _cmp(emu, oracle, fa + ".img", reads[:2])
 
 

@@ -175,3 +175,36 @@ def test_units_emu_chain_flt(oracle):
 @pytest.mark.gpu
 def test_units_gpu_chain_flt(oracle):
     _check_chain_flt(_load("hip"), oracle, 300, 1500)
+
+
+def _check_sort_regs(units, n_cases, max_n):
+    """the regions sorted through key records must come out in the very permutation the sort of the regions themselves gives
+    (ties included: the record index travels in `pad_`)"""
+    assert units.unit_sizeof_alnreg() == 96
+    reg = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("rid", "<i4"), ("score", "<i4"), ("mid", "<i4", 10),
+                    ("n_comp", "<i4"), ("is_alt", "<i4"), ("frac_rep", "<f4"), ("pad_", "<i4"), ("hash", "<u8")])
+    assert reg.itemsize == 96
+    units.unit_sort_regs.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    rng = np.random.default_rng(41)
+    for it in range(n_cases):
+        n = int(rng.integers(1, max_n))
+        a = np.zeros(n, dtype=reg)
+        few = int(rng.choice([2, 5, 1000000]))                                  # many ties ... hardly any
+        a["re"] = rng.integers(-3, few, size=n); a["rb"] = rng.integers(0, few, size=n); a["qb"] = rng.integers(-2, min(few, 150), size=n)
+        a["score"] = rng.integers(-1, min(few, 151), size=n); a["is_alt"] = rng.integers(0, 2, size=n)
+        a["hash"] = rng.integers(0, few, size=n, dtype=np.uint64) << np.uint64(int(rng.choice([0, 40, 63])))
+        a["pad_"] = np.arange(n)
+        for which in range(4):
+            x, y = a.copy(), a.copy()
+            assert units.unit_sort_regs(n, x.ctypes.data, which, 0) == 0 and units.unit_sort_regs(n, y.ctypes.data, which, 1) == 0
+            assert x.tobytes() == y.tobytes(), (it, n, which, few)
+            assert sorted(x["pad_"].tolist()) == list(range(n))
+
+
+def test_units_emu_sort_regs():
+    _check_sort_regs(_load("emu"), 12, 300)
+
+
+@pytest.mark.gpu
+def test_units_gpu_sort_regs():
+    _check_sort_regs(_load("hip"), 150, 3000)
