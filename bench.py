@@ -377,6 +377,9 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         launch_ranks(args.gpus)
 
+    # libbwamem_hip.so asks the HIP runtime for eight hardware queues when it is the process's first HIP user (a JVM); here torch
+    # initialises HIP first, so the same default is set before that happens (pipeline.cpp: hip_runtime_defaults)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import numpy as np
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -612,7 +615,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32/int64", "data": "synthetic",
             "config": {"workload": "%d x %dbp %s synthetic reads per GPU vs %s, full index in HBM" % (R, L, "paired-end (2 x %d pairs)" % (R // 2) if args.paired else "single-end ONT-style (8 %% sub, 3 %% ins, 3 %% del)" if args.ont else "single-end", genome_desc),
                        "reads_per_gpu": R, "read_len": L, "genome_bp": args.genome_bp, "genome": "image" if args.image else args.genome, "index_build_s": round(t_index, 1), "response_bytes": result_bytes,
-                       "parallelism": "read-sharded x%d, no collectives" % world, "paired_end": bool(args.paired), "insert_size_statistics": ("supplied " + args.pestat) if (args.paired and args.pestat) else ("inferred per call" if args.paired else None),
+                       "parallelism": "read-sharded x%d, no collectives" % world, "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "paired_end": bool(args.paired), "insert_size_statistics": ("supplied " + args.pestat) if (args.paired and args.pestat) else ("inferred per call" if args.paired else None),
                        "value_is": "device-resident rate: request already in HBM when the timed region starts, response left in HBM (the bench contract); the rate through jnibwa_createAlignments itself is `host_to_host`"},
             "per_rank": {"reads_per_s": [R * args.steps / x for x in per_rank], "ms_per_step_min": min(per_rank) / args.steps * 1e3, "ms_per_step_max": max(per_rank) / args.steps * 1e3},
             "host_to_host": h2h,

@@ -181,6 +181,25 @@ DEV int chain_weight(const Chain& c, const Seed* seeds)
 }
 
 struct ChainWLt { __device__ bool operator()(const Chain& a, const Chain& b) const { return a.w > b.w; } };
+// The weight sort through 8-byte records {weight, index} (chain weights tie all the time and the introsort is unstable: the
+// comparator sees the weight only, so the records take the very permutation the 40-byte chains would, and each chain then
+// moves once).  recs: n records of scratch.
+struct ChainRec { uint32_t w; int32_t idx; };
+struct ChainRecLt { __device__ bool operator()(const ChainRec& a, const ChainRec& b) const { return a.w > b.w; } };
+DEV void sort_chains_by_weight(int n, Chain* a, ChainRec* recs)
+{
+    if (n < 12) { ks_introsort((size_t)n, a, ChainWLt()); return; }
+    for (int i = 0; i < n; ++i) { ChainRec k; k.w = a[i].w; k.idx = i; recs[i] = k; }
+    ks_introsort((size_t)n, recs, ChainRecLt());
+    for (int i = 0; i < n; ++i) {
+        int src = recs[i].idx;
+        if (src == i) continue;
+        const Chain first = a[i];
+        int j = i;
+        while (src != i) { a[j] = a[src]; recs[j].idx = j; j = src; src = recs[j].idx; }
+        a[j] = first; recs[j].idx = j;
+    }
+}
 
 // chaining + chain weights + the weight sort of one read (one lane).  Returns the number of chains that enter mem_chain_flt's
 // overlap loop (sorted in a[]), 0 when the read has none.  kept: room for the packed kept chains, in the B-tree's node pool
@@ -234,7 +253,7 @@ DEV int chain_build(const DevIndex& ix, const MemOpt& opt, const TileView& tv, C
     n_chn = k;
     if (n_chn == 0) return 0;
     const int kept_cap = (int)(((size_t)bt.cap_nodes * BT_NODE_INTS * 4 - 16) / 16);
-    ks_introsort((size_t)n_chn, a, ChainWLt());
+    sort_chains_by_weight(n_chn, a, (ChainRec*)cs);          // cs (the chains in creation order) is dead since the traversal
     if (n_chn > kept_cap) { atomicOr(tv.err, ERR_BTREE); return 0; }
     return n_chn;
 }

