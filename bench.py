@@ -306,7 +306,7 @@ def parse_args():
     ap.add_argument("--contigs", type=int, default=24)
     ap.add_argument("--genome", choices=["iid", "humanlike"], default="iid", help="iid: i.i.d. bases + 5 %% diverged copies (SURVEY.md 8(d)); humanlike: "
                     "~45 %% of the bases in repeat families (SINE-, LINE-like, satellites, low complexity)")
-    ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads timed through the CPU checker (rank 0, N=1), best of --cpu-reps")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="reads timed through the CPU checker (rank 0, N=1), best of --cpu-reps; default 400 000 (5 000 with --ont: about 15 s of CPU work either way)")
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--h2h-calls", type=int, default=3, help="whole-batch jnibwa_createAlignments calls (host request in, host response out) after the timed steps; the first one sizes buffers, the best of the rest is reported; 0 = skip")
     ap.add_argument("--paired", action="store_true", help="auxiliary measurement (BASELINE.json config 2): --reads is then the number of reads = 2 x pairs; "
@@ -319,7 +319,10 @@ def parse_args():
     ap.add_argument("--dump-request", default=None, help="write the first --cpu-sample reads as a request file (profiling helper)")
     ap.add_argument("--image", default=os.environ.get("BWAHIP_REF_IMG"), help="use an existing .img (e.g. GATK's Homo_sapiens_assembly38.fasta.img) instead of "
                     "the synthetic genome; reads are sampled from its packed reference (default: $BWAHIP_REF_IMG)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.cpu_sample is None:
+        args.cpu_sample = 5_000 if args.ont else 400_000
+    return args
 
 
 def launch_ranks(n):
@@ -500,6 +503,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    note("%d warm-up steps done" % args.warmup)
     lib.bwamem_hip_stats_enable(1)
     lib.bwamem_hip_stats_reset()
     barrier()
@@ -513,6 +517,7 @@ def main():
     st_timed = Stats(); lib.bwamem_hip_stats_get(ctypes.byref(st_timed))
     lib.bwamem_hip_stats_enable(0)
     result_bytes = lib.bwamem_hip_batch_result_bytes(batch)
+    note("%d timed steps done (%.1f ms per step)" % (args.steps, elapsed / args.steps * 1e3))
 
     # ---- the same batch through the drop-in entry point itself: jnibwa_createAlignments, host request in, malloc'ed host
     # response out (jnibwa.c:197-235) -- every rank at once, so that at N > 1 the ranks share the host's memory and PCIe
@@ -542,6 +547,7 @@ def main():
                 got = np.ctypeslib.as_array(ctypes.cast(gp, ctypes.POINTER(ctypes.c_ubyte)), shape=(max(sz.value, 1),))
                 same = bool(sz.value == result_bytes and np.array_equal(got[:sz.value], resident[:result_bytes]))
             lib.jnibwa_free(gp)
+            note("jnibwa_createAlignments call %d of %d: %.3f s" % (k + 1, args.h2h_calls, secs[-1]))
         best = min(secs[1:]) if len(secs) > 1 else secs[0]
         h2h = {"reads_per_s": world * R / best, "seconds_per_call": [round(x, 4) for x in secs], "calls": args.h2h_calls,
                "request_bytes_per_gpu": int(full.nbytes), "response_bytes_per_gpu": int(h2h_bytes), "identical_to_resident_response": same,
@@ -579,6 +585,7 @@ def main():
     step()
     torch.cuda.synchronize()
     st = Stats(); lib.bwamem_hip_stats_get(ctypes.byref(st))
+    note("roofline pass (one tile in flight) done")
     del os.environ["BWAMEM_HIP_SEED_AHEAD"]
     if streams_env is None:
         del os.environ["BWAMEM_HIP_STREAMS"]
@@ -650,6 +657,7 @@ def main():
             tc = time.time()
             want = orc.align_raw(ho, oo, req, pes)
             tcs.append(time.time() - tc)
+            note("CPU checker: %d reads in %.1f s" % (S, tcs[-1]))
         tcpu = min(tcs)
         orc.destroy_index(ho)
         rb = ctypes.create_string_buffer(req, len(req)); sz = ctypes.c_size_t()

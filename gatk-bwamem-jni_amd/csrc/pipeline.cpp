@@ -883,6 +883,9 @@ struct CallPipe {
 // for most of the launch.  The first chunks are small (one tile, then two, ...) so that the tile workers start early.
 static void append_stretch(CallPipe& pp, const ReqChunk& rc, const MemOpt& opt, bool even, int tile_scale)
 {
+    // the larger tile is for short reads in repeats; long reads carry thousands of seeds each whatever the reference, and twice
+    // their workspaces does not fit four times next to the index
+    { const uint32_t n = rc.r1 - rc.r0; if (n && (rc.h_off[n] - rc.h_off[0]) / n > 1000) tile_scale = 1; }
     std::vector<TileSpec> tiles;
     plan_tiles(rc, opt, even, false, tile_scale, tiles);
     const char* e = getenv("BWAMEM_HIP_SEED_CHUNK");
