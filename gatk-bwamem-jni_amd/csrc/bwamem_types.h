@@ -117,7 +117,7 @@ struct DevCounters {
 };
 
 // per-tile error / overflow flags set by kernels, read back by the host after each stage
-enum { ERR_INTV_CAP = 1, ERR_OUT_CAP = 2, ERR_CIGAR_CAP = 4, ERR_LONG_READ = 8, ERR_SCRATCH = 16, ERR_BTREE = 32, ERR_BAD_REG = 64, ERR_JOB_CAP = 128, ERR_ZPOOL = 256 };
+enum { ERR_INTV_CAP = 1, ERR_OUT_CAP = 2, ERR_CIGAR_CAP = 4, ERR_LONG_READ = 8, ERR_SCRATCH = 16, ERR_BTREE = 32, ERR_BAD_REG = 64, ERR_JOB_CAP = 128, ERR_ZPOOL = 256, ERR_RESCUE_CAP = 512 };
 
 #define BT_NODE_INTS 40          // ints per node of the chaining B-tree (k_chain.hip); the pool doubles as per-read scratch later
 

@@ -317,7 +317,7 @@ __global__ void k_pe_rescue_plan(DevIndex ix, MemOpt opt, TileView tv, PeView pv
             cnt = k;
             if (cnt > 0) {
                 first = atomicAdd(counter, cnt);
-                if (first + cnt > cap) { atomicOr(tv.err, ERR_JOB_CAP); cnt = 0; }
+                if (first + cnt > cap) { atomicOr(tv.err, ERR_RESCUE_CAP); cnt = 0; }     // the list is then incomplete *and* has unwritten slots below cap: nobody may run it
             }
             if (cnt == 0) break;
         }
@@ -334,6 +334,7 @@ __global__ void __launch_bounds__(64) k_pe_rescue_sw(DevIndex ix, MemOpt opt, Ti
     HIP_DYNAMIC_SHARED(uint64_t, blists)
     constexpr int PER = 64 / GW;                                 // alignments per wavefront: 4 in byte mode (GW = 16), 8 in 16-bit mode (GW = 8)
     const int lane = threadIdx.x;
+    if (tv.err[0] & ERR_RESCUE_CAP) return;                      // the job list did not fit: the host sizes it from the count and runs the stage again
     const int n = *counter < cap ? *counter : cap;
     if ((int)blockIdx.x * PER >= n) return;
     const int job = blockIdx.x * PER + lane / GW;
@@ -363,6 +364,8 @@ __global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPe
 {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
     if (pi >= tv.n_reads >> 1) return;
+    if (tv.err[0] & ERR_RESCUE_CAP) return;                      // rescue list incomplete (see k_pe_rescue_plan): this attempt is void, and without the
+                                                                 // precomputed alignments every lane would run them itself, one cell at a time
     const MemPestat pes[4] = { p0, p1, p2, p3 };
     PeCtx c = pe_ctx(tv, pv, pi);
     const int* rd = c.rd; const uint8_t** seq = c.seq; int* l_seq = c.l_seq; AlnReg** a = c.a; int* n = c.n; int* cap = c.cap; int32_t** zb = c.zb;

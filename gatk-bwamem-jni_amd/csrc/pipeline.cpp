@@ -211,6 +211,17 @@ struct CapHints {
         std::lock_guard<std::mutex> lk(mu);
         jobs = (int)std::min(1.0e9, jobs_per_read * T) + 1; zpool_mult_ = zpool_mult; out_cap_ = out_cap;
     }
+    // paired-end phase 2: mate-rescue alignments and global-alignment jobs per read of the tiles seen so far (pairs in repeats ask
+    // for hundreds of rescue alignments; a tile sized for the easy case runs its stage twice)
+    double pe_rescue_per_read = 0, pe_jobs_per_read = 0;
+    void learn_pe(int T, int n_rescue, int n_jobs) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (T >= 64) { pe_rescue_per_read = std::max(pe_rescue_per_read, 1.25 * n_rescue / T); pe_jobs_per_read = std::max(pe_jobs_per_read, 1.25 * n_jobs / T); }
+    }
+    void get_pe(int T, int& rescue, int& jobs) {
+        std::lock_guard<std::mutex> lk(mu);
+        rescue = (int)std::min(1.0e9, pe_rescue_per_read * T) + 1; jobs = (int)std::min(1.0e9, pe_jobs_per_read * T) + 1;
+    }
 };
 
 struct bwaidx_s {
@@ -1151,6 +1162,7 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
     RoctxRange rr("bwamem_hip:tile_pe_phase2");
     const int T = pt->T, L = pt->L;
     int attempts = 0, cap_u = 256, pe_job_cap = 0, pe_rescue_cap = 0;
+    ix->hints.get_pe(T, pe_rescue_cap, pe_job_cap);
     size_t pe_zpool = 0;
     for (;;) {
         if (++attempts > 8) { fprintf(stderr, "[bwamem_hip] paired-end tile could not be sized\n"); return false; }
@@ -1185,7 +1197,8 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
         }
         PE_OK(hipMemsetAsync(ws.job_cnt.p, 0, 64, ws.stream));
         {   // rescue alignments: a few per cent of the pairs ask for one, pairs in repeats for many
-            const int rc = std::max(pe_rescue_cap, std::max(4096, T / 8));
+            static const int floor0 = []{ const char* e = getenv("BWAMEM_HIP_PE_RESCUE_CAP0"); return e && atoi(e) > 0 ? atoi(e) : 4096; }();   // test knob: start small, take the resize path
+            const int rc = std::max(pe_rescue_cap, floor0 < 4096 ? floor0 : std::max(4096, T / 8));
             PE_REQ(ws.pe_rescue[0].ensure(pe_rescue_bytes(0, rc)) && ws.pe_rescue[1].ensure(pe_rescue_bytes(1, rc)) && ws.pe_rescue[2].ensure((size_t)(T / 2 + 1) * 8 + 64));
             pe_rescue_cap = rc;
         }
@@ -1198,7 +1211,8 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
         PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
         PE_OK(hipMemcpyAsync(&n_rescue, ws.pe_rescue[2].p, 4, hipMemcpyDeviceToHost, ws.stream));
         PE_OK(hipStreamSynchronize(ws.stream));
-        if (n_rescue > pe_rescue_cap) { pe_rescue_cap = n_rescue + n_rescue / 4; continue; }
+        if (n_rescue > pe_rescue_cap) { pe_rescue_cap = n_rescue + n_rescue / 4; continue; }     // (the kernels after the plan saw ERR_RESCUE_CAP and did nothing)
+        ix->hints.learn_pe(T, n_rescue, n_jobs);
         if ((err & ERR_JOB_CAP) || n_jobs > ws.job_cap) { pe_job_cap = std::max(n_jobs + n_jobs / 4, ws.job_cap * 2); continue; }
         if (err & ERR_SCRATCH) { cap_u *= 8; if (attempts < 4) continue; }
         if (err) { fprintf(stderr, "[bwamem_hip] device error flags %d in the paired-end pairing stage\n", err); return false; }

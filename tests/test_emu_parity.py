@@ -248,3 +248,36 @@ def test_emu_scan_forms(emu, monkeypatch):
             scan(None, x.ctypes.data, out.ctypes.data, n, tmp.ctypes.data)
             want = np.concatenate([[0], np.cumsum(x.astype(np.int64))])
             assert (out == want).all(), (single_max, fused_max, n)
+
+
+def test_emu_mate_rescue_list_resized(oracle, small_genome):
+    """the mate-rescue job list of a tile is sized from earlier tiles; when it does not fit, the plan kernel flags it and the
+    alignment and pairing kernels must not run on the half-written list (its unwritten slots hold whatever the memory held).
+    Own process: the floor of the list size is read once.  The call is repeated so that the learned size is used as well."""
+    import subprocess
+    import sys
+    B.build_emu()
+    seqs, img = small_genome
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import bwalib as B
+emu, orc = B.product_lib(emu=True), B.oracle_lib()
+seqs = []
+for blk in open(%r).read().split(">")[1:]:
+    name, _, body = blk.partition("\n")
+    seqs.append((name.strip(), body.replace("\n", "").encode()))
+pairs = B.simulate_pairs(seqs, 30, length=100, seed=77, ins_mean=300, ins_sd=30, sub=0.05)
+for k in range(1, len(pairs), 4):                       # mates that only a rescue can place
+    pairs[k] = pairs[k][:30] + B.revcomp(pairs[k][30:70]) + pairs[k][70:]
+h, ho = emu.open_index(%r), orc.open_index(%r)
+opts = B.set_opt(emu.default_options(), flag=B.MEM_F_PE)
+req = B.pack_request(pairs)
+want = orc.align_raw(ho, opts, req)
+for _ in range(2):
+    assert emu.align_raw(h, opts, req) == want
+print("rescue-resize-ok")
+''' % (os.path.join(B.ROOT, "tests"), img[:-4] if img.endswith(".img") else img, img, img)
+    env = dict(os.environ, BWAMEM_HIP_PE_RESCUE_CAP0="3")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "rescue-resize-ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
