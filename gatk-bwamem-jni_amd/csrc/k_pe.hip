@@ -103,7 +103,7 @@ DEV void rescue_skip(const DevIndex& ix, const MemPestat* pes, const AlnReg& a, 
 // mem_matesw for one anchor; the alignments come from the job list of the pair (jobs[q .. q_end), in tag order)
 DEV int matesw(const DevIndex& ix, const MemOpt& opt, PostScratch& S, SwScratch& W, const MemPestat* pes, const AlnReg& a,
                int l_ms, const uint8_t* ms, int& n_ma, AlnReg* ma, int cap_ma, int& err,
-               const RescueJob* jobs, const KswR* results, int& q, int q_end, int tag0)
+               const RescueJob* jobs, const KswR* results, int& q, int q_end, int tag0, SortKey* keys = nullptr)
 {
     const int64_t l_pac = ix.l_pac;
     int i, r, skip[4], n = 0;
@@ -144,7 +144,7 @@ DEV int matesw(const DevIndex& ix, const MemOpt& opt, PostScratch& S, SwScratch&
             }
             ++n;
         }
-        if (n) n_ma = sort_dedup_patch(ix, opt, S, 0, n_ma, ma);
+        if (n) n_ma = sort_dedup_patch(ix, opt, S, 0, n_ma, ma, 0, keys);
     }
     return n;
 }
@@ -232,6 +232,7 @@ struct PeView {
     uint8_t* scratch;         // per pair
     int64_t scratch_per_pair;
     void* vpool;              // Pair64 per region slot (indexed by reg_off of the pair's first read)
+    void* keys;               // SortKey per region slot (post_common.h: sort_regs), or null
     int cap_h, cap_b, cap_u;
     PairTab ptab;             // host-built insert-size score terms (mem_pair)
 };
@@ -376,6 +377,10 @@ __global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPe
     Pair64* u = P.u;
     const int cap_u = pv.cap_u;
 
+    // key records for the region sorts of each end (a pair in a repeat family sorts hundreds of regions once per rescued anchor)
+    // (offsets, not an array of pointers: a pointer reloaded from private memory loses its address space)
+    SortKey* const kbase = pv.keys && !(tv.debug & 0x400) ? (SortKey*)pv.keys : nullptr;
+    const int64_t koff[2] = { pv.reg_off[rd[0]], pv.reg_off[rd[1]] };
     const uint64_t id = (uint64_t)((tv.read_id0 >> 1) + pi);
     int z[2] = { 0, 0 }, o = 0, subo = 0, n_sub = 0, extra_flag = 1, n_pri[2], q_se[2] = { 0, 0 };
     if (!(opt.flag & MEM_F_NO_RESCUE)) {                       // mate rescue from the best hits of each end
@@ -385,10 +390,10 @@ __global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPe
         const int q_end = q + job_num[pi];
         for (int i = 0; i < 2; ++i)
             for (int j = 0; j < n_anch[i] && j < opt.max_matesw; ++j)
-                matesw(ix, opt, S, P.W, pes, P.anchors[i][j], l_seq[!i], seq[!i], n[!i], a[!i], cap[!i], err, rjobs, rres, q, q_end, i << 16 | j << 2);
+                matesw(ix, opt, S, P.W, pes, P.anchors[i][j], l_seq[!i], seq[!i], n[!i], a[!i], cap[!i], err, rjobs, rres, q, q_end, i << 16 | j << 2, kbase ? kbase + koff[!i] : nullptr);
     }
-    n_pri[0] = mark_primary_se(opt, n[0], a[0], (int64_t)(id << 1 | 0), zb[0]);
-    n_pri[1] = mark_primary_se(opt, n[1], a[1], (int64_t)(id << 1 | 1), zb[1]);
+    n_pri[0] = mark_primary_se(opt, n[0], a[0], (int64_t)(id << 1 | 0), zb[0], kbase ? kbase + koff[0] : nullptr);
+    n_pri[1] = mark_primary_se(opt, n[1], a[1], (int64_t)(id << 1 | 1), zb[1], kbase ? kbase + koff[1] : nullptr);
     if (opt.flag & MEM_F_PRIMARY5) { reorder_primary5(opt.T, n[0], a[0]); reorder_primary5(opt.T, n[1], a[1]); }
 
     bool paired = false;
@@ -618,13 +623,13 @@ void launch_pe_copy_regs(hipStream_t st, const TileView& tv, const AlnReg* src, 
 }
 // mate rescue steps 1 and 2 + the pairing stage.  rescue: RescueJob[cap], KswR[cap], per-pair first/count, a counter (zeroed here)
 void launch_pe_pair(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, AlnReg* regs, const int64_t* reg_off,
-                    int32_t* n_regs, int32_t* ints, void* vpool, uint8_t* scratch, int64_t scratch_per_pair, int cap_h, int cap_b, int cap_u, const MemPestat* pes, const PairTab& ptab, void* states,
+                    int32_t* n_regs, int32_t* ints, void* vpool, void* keys, uint8_t* scratch, int64_t scratch_per_pair, int cap_h, int cap_b, int cap_u, const MemPestat* pes, const PairTab& ptab, void* states,
                     void* rescue_jobs, void* rescue_res, int32_t* rescue_first, int32_t* rescue_num, int32_t* rescue_cnt, int rescue_cap)
 {
     int np = tv.n_reads >> 1;
     hipLaunchKernelGGL(k_pe_tail, dim3(1), dim3(64), 0, st, tv);
     if (np <= 0) return;
-    PeView pv; pv.regs = regs; pv.reg_off = reg_off; pv.n_regs = n_regs; pv.ints = ints; pv.vpool = vpool; pv.scratch = scratch;
+    PeView pv; pv.regs = regs; pv.reg_off = reg_off; pv.n_regs = n_regs; pv.ints = ints; pv.vpool = vpool; pv.keys = keys; pv.scratch = scratch;
     pv.scratch_per_pair = scratch_per_pair; pv.cap_h = cap_h; pv.cap_b = cap_b; pv.cap_u = cap_u; pv.ptab = ptab;
     (void)hipMemsetAsync(rescue_cnt, 0, 4, st);
     if (!(opt.flag & MEM_F_NO_RESCUE)) {

@@ -35,7 +35,7 @@ void launch_pestat_cand(hipStream_t st, const DevIndex& ix, const MemOpt& opt, c
 void launch_pe_caps(hipStream_t st, const MemOpt& opt, const TileView& tv, int32_t* caps);
 void launch_pe_copy_regs(hipStream_t st, const TileView& tv, const AlnReg* src, const int64_t* src_off, AlnReg* dst, const int64_t* dst_off, const int32_t* n_regs);
 void launch_pe_pair(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, AlnReg* regs, const int64_t* reg_off,
-                    int32_t* n_regs, int32_t* ints, void* vpool, uint8_t* scratch, int64_t scratch_per_pair, int cap_h, int cap_b, int cap_u, const MemPestat* pes, const PairTab& ptab, void* states,
+                    int32_t* n_regs, int32_t* ints, void* vpool, void* keys, uint8_t* scratch, int64_t scratch_per_pair, int cap_h, int cap_b, int cap_u, const MemPestat* pes, const PairTab& ptab, void* states,
                     void* rescue_jobs, void* rescue_res, int32_t* rescue_first, int32_t* rescue_num, int32_t* rescue_cnt, int rescue_cap);
 size_t pe_rescue_bytes(int what, int cap);       // what = 0: SwJob[cap], 1: KswR[cap]
 void launch_sw_jobs(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const TileView& tv, const void* jobs, const int32_t* cnt, int cap, void* results, int cap_b, int max_qlen);

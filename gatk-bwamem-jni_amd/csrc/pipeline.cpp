@@ -214,13 +214,15 @@ struct CapHints {
     // paired-end phase 2: mate-rescue alignments and global-alignment jobs per read of the tiles seen so far (pairs in repeats ask
     // for hundreds of rescue alignments; a tile sized for the easy case runs its stage twice)
     double pe_rescue_per_read = 0, pe_jobs_per_read = 0;
-    void learn_pe(int T, int n_rescue, int n_jobs) {
+    int pe_cap_u = 256;                             // candidate pairs per pair in mem_pair's list (a pair inside a tandem array has thousands)
+    void learn_pe(int T, int n_rescue, int n_jobs, int cap_u) {
         std::lock_guard<std::mutex> lk(mu);
         if (T >= 64) { pe_rescue_per_read = std::max(pe_rescue_per_read, 1.25 * n_rescue / T); pe_jobs_per_read = std::max(pe_jobs_per_read, 1.25 * n_jobs / T); }
+        pe_cap_u = std::min(2048, std::max(pe_cap_u, cap_u));      // (16 bytes each for every pair of a tile: larger lists stay a per-tile retry)
     }
-    void get_pe(int T, int& rescue, int& jobs) {
+    void get_pe(int T, int& rescue, int& jobs, int& cap_u) {
         std::lock_guard<std::mutex> lk(mu);
-        rescue = (int)std::min(1.0e9, pe_rescue_per_read * T) + 1; jobs = (int)std::min(1.0e9, pe_jobs_per_read * T) + 1;
+        rescue = (int)std::min(1.0e9, pe_rescue_per_read * T) + 1; jobs = (int)std::min(1.0e9, pe_jobs_per_read * T) + 1; cap_u = pe_cap_u;
     }
 };
 
@@ -1162,7 +1164,7 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
     RoctxRange rr("bwamem_hip:tile_pe_phase2");
     const int T = pt->T, L = pt->L;
     int attempts = 0, cap_u = 256, pe_job_cap = 0, pe_rescue_cap = 0;
-    ix->hints.get_pe(T, pe_rescue_cap, pe_job_cap);
+    ix->hints.get_pe(T, pe_rescue_cap, pe_job_cap, cap_u);
     size_t pe_zpool = 0;
     for (;;) {
         if (++attempts > 8) { fprintf(stderr, "[bwamem_hip] paired-end tile could not be sized\n"); return false; }
@@ -1182,7 +1184,7 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
         for (int d = 0; d < 4; ++d) if (!pes[d].failed) span = std::max(span, pes[d].high - pes[d].low);
         const int cap_h = L + 32, cap_b = (span + 2 * L) / 2 + 16;
         const int64_t per_pair = (((int64_t)16 * cap_h + (int64_t)8 * cap_b + (int64_t)2 * opt.max_matesw * sizeof(AlnReg) + (int64_t)16 * cap_u) + 63) & ~(int64_t)63;
-        PE_REQ(ws.pe_regs2.ensure((size_t)(tot + 1) * sizeof(AlnReg)) && ws.pe_ints2.ensure((size_t)(tot + 1) * 8) && ws.pe_vpool.ensure((size_t)(tot + 2) * 16)
+        PE_REQ(ws.pe_regs2.ensure((size_t)(tot + 1) * sizeof(AlnReg)) && ws.pe_ints2.ensure((size_t)(tot + 1) * 8) && ws.pe_vpool.ensure((size_t)(tot + 2) * 16 + 64 + (size_t)(tot + 2) * 24)
                && ws.pe_scratch.ensure((size_t)((T >> 1) + 1) * (size_t)per_pair));
         AlnReg* regs2 = ws.pe_regs2.as<AlnReg>(); int64_t* reg_off2 = ws.pe_reg_off2.as<int64_t>();
         TIMED(ws, K_OTHER, launch_pe_copy_regs(ws.stream, tv, pt->regs.as<AlnReg>(), pt->reg_off.as<int64_t>(), regs2, reg_off2, tv.n_regs));
@@ -1202,7 +1204,7 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
             PE_REQ(ws.pe_rescue[0].ensure(pe_rescue_bytes(0, rc)) && ws.pe_rescue[1].ensure(pe_rescue_bytes(1, rc)) && ws.pe_rescue[2].ensure((size_t)(T / 2 + 1) * 8 + 64));
             pe_rescue_cap = rc;
         }
-        TIMED(ws, K_FINAL, launch_pe_pair(ws.stream, ix->d, opt, tv, regs2, reg_off2, tv.n_regs, ws.pe_ints2.as<int32_t>(), ws.pe_vpool.p,
+        TIMED(ws, K_FINAL, launch_pe_pair(ws.stream, ix->d, opt, tv, regs2, reg_off2, tv.n_regs, ws.pe_ints2.as<int32_t>(), ws.pe_vpool.p, (char*)ws.pe_vpool.p + (((size_t)(tot + 2) * 16 + 63) & ~(size_t)63),
                                           ws.pe_scratch.as<uint8_t>(), per_pair, cap_h, cap_b, cap_u, pes, ix->pair_tab, ws.pe_states.p,
                                           ws.pe_rescue[0].p, ws.pe_rescue[1].p, ws.pe_rescue[2].as<int32_t>() + 16, ws.pe_rescue[2].as<int32_t>() + 16 + (T / 2 + 1),
                                           ws.pe_rescue[2].as<int32_t>(), pe_rescue_cap));
@@ -1212,7 +1214,7 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
         PE_OK(hipMemcpyAsync(&n_rescue, ws.pe_rescue[2].p, 4, hipMemcpyDeviceToHost, ws.stream));
         PE_OK(hipStreamSynchronize(ws.stream));
         if (n_rescue > pe_rescue_cap) { pe_rescue_cap = n_rescue + n_rescue / 4; continue; }     // (the kernels after the plan saw ERR_RESCUE_CAP and did nothing)
-        ix->hints.learn_pe(T, n_rescue, n_jobs);
+        ix->hints.learn_pe(T, n_rescue, n_jobs, cap_u);
         if ((err & ERR_JOB_CAP) || n_jobs > ws.job_cap) { pe_job_cap = std::max(n_jobs + n_jobs / 4, ws.job_cap * 2); continue; }
         if (err & ERR_SCRATCH) { cap_u *= 8; if (attempts < 4) continue; }
         if (err) { fprintf(stderr, "[bwamem_hip] device error flags %d in the paired-end pairing stage\n", err); return false; }

@@ -1,10 +1,10 @@
 ulimit -c 0
-timeout -k 10 500 python bench.py --paired --genome humanlike --reads 600000 --steps 2 --warmup 1 --h2h-calls 3 --cpu-sample 60000 --cpu-reps 1 > gpurun_out/pehl_fix.json 2> gpurun_out/pehl_fix.err
-echo "rc=$?"
-grep -v "^\[bench\] *[0-9.]*s \(synth\|suffix\|index\)" gpurun_out/pehl_fix.err | tail -8 | cut -c1-250
-python - <<PY
+for dk in 8192 16384 32768; do
+BWAMEM_HIP_DEBUGK=$dk timeout -k 10 300 python bench.py --paired --genome humanlike --reads 600000 --steps 1 --warmup 1 --h2h-calls 0 --cpu-sample 0 > gpurun_out/q.json 2> gpurun_out/q.err
+python - $dk <<PY
 import json,sys
 try:
-    d=json.load(open("gpurun_out/pehl_fix.json")); print(round(d["value"]), round(d["ms_per_step"],1), d["host_to_host"]["seconds_per_call"], d["cpu_baseline"]["value"], d.get("parity_sample"), d["kernel_ms_isolated_pass"], d["counters"])
+    d=json.load(open("gpurun_out/q.json")); print(sys.argv[1], round(d["ms_per_step"],1), d["kernel_ms_isolated_pass"]["final"])
 except Exception as e: print("no json", e)
 PY
+done
