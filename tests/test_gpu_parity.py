@@ -513,3 +513,21 @@ def test_bench_on_an_existing_image_with_a_stock_library_hook(small_genome, tmp_
     assert out["config"]["genome"] == "image" and out["config"]["genome_bp"] == sum(len(s) for _, s in seqs)
     assert out["cpu_baseline"]["kind"] == "reference" and out["parity_sample"]["frac_identical_records"] == 1.0
     assert out["host_to_host"]["identical_to_resident_response"] is True
+
+
+def test_paired_end_on_repeat_rich_genome(tmp_path):
+    """Pairs drawn from a genome with human-like repeat content (bench.py --genome humanlike, scaled down): reads carry many
+    regions, pairs ask for far more mate-rescue alignments than a tile's first guess holds, so the rescue job list is resized
+    (the path that once ran half-written lists: an illegal memory access on the device), and the records must still be the
+    oracle's.  Two calls through jnibwa_createAlignments as well: sizes learned from the first one."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(B.ROOT, "bench.py"), "--paired", "--genome", "humanlike", "--genome-bp", "16000000", "--contigs", "3",
+                        "--reads", "60000", "--steps", "1", "--warmup", "1", "--cpu-sample", "60000", "--cpu-reps", "1", "--h2h-calls", "2"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["parity_sample"]["reads"] == 60000 and out["parity_sample"]["frac_identical_records"] == 1.0, out["parity_sample"]
+    assert out["host_to_host"]["identical_to_resident_response"] is True
