@@ -100,10 +100,12 @@ DEV void rescue_skip(const DevIndex& ix, const MemPestat* pes, const AlnReg& a, 
     }
 }
 
-// mem_matesw for one anchor; the alignments come from the job list of the pair (jobs[q .. q_end), in tag order)
+// mem_matesw for one anchor; the alignments come from the job list of the pair (jobs[q .. q_end), in tag order).
+// settled: the mate's list has been through mem_sort_dedup_patch (with at least two regions) since it was last touched by
+// anything else; incr: use matesw_insert (off: BWAMEM_HIP_DEBUGK bit 0x800, every call runs the procedure itself)
 DEV int matesw(const DevIndex& ix, const MemOpt& opt, PostScratch& S, SwScratch& W, const MemPestat* pes, const AlnReg& a,
                int l_ms, const uint8_t* ms, int& n_ma, AlnReg* ma, int cap_ma, int& err,
-               const RescueJob* jobs, const KswR* results, int& q, int q_end, int tag0, SortKey* keys = nullptr)
+               const RescueJob* jobs, const KswR* results, int& q, int q_end, int tag0, SortKey* keys, bool& settled, bool incr, int* stat)
 {
     const int64_t l_pac = ix.l_pac;
     int i, r, skip[4], n = 0;
@@ -113,6 +115,8 @@ DEV int matesw(const DevIndex& ix, const MemOpt& opt, PostScratch& S, SwScratch&
         if (skip[r]) continue;
         int is_rev, xtra;
         int64_t rb, re;
+        bool ins = false;
+        AlnReg b;
         if (rescue_req(ix, opt, pes, a, r, l_ms, rb, re, is_rev, xtra)) {
             KswR aln; aln.score = RESCUE_NOT_RUN;
             while (q < q_end && jobs[q].tag < (tag0 | r)) ++q;
@@ -122,7 +126,6 @@ DEV int matesw(const DevIndex& ix, const MemOpt& opt, PostScratch& S, SwScratch&
                 aln = sw_align2(ix, opt, I, l_ms, (int)(re - rb), xtra, W, err);
             }
             if (aln.score >= opt.min_seed_len && aln.qb >= 0) {
-                AlnReg b;
                 b.rb = b.re = 0; b.qb = b.qe = 0; b.rid = 0; b.score = b.truesc = b.sub = b.alt_sc = b.csub = b.sub_n = b.w = b.seedcov = 0;
                 b.secondary = b.secondary_all = b.seedlen0 = b.n_comp = b.is_alt = 0; b.frac_rep = 0.f; b.pad_ = 0; b.hash = 0;
                 b.rid = a.rid;
@@ -136,15 +139,25 @@ DEV int matesw(const DevIndex& ix, const MemOpt& opt, PostScratch& S, SwScratch&
                 b.secondary = -1;
                 b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
                 if (n_ma >= cap_ma) { err |= ERR_SCRATCH; return n; }
-                ++n_ma;
-                for (i = 0; i < n_ma - 1; ++i) if (ma[i].score < b.score) break;
-                int tmp = i;
-                for (i = n_ma - 1; i > tmp; --i) ma[i] = ma[i - 1];
-                ma[i] = b;
+                ins = true;
             }
             ++n;
         }
-        if (n) n_ma = sort_dedup_patch(ix, opt, S, 0, n_ma, ma, 0, keys);
+        if (ins) ++stat[0];
+        if (ins && !(incr && settled && n_ma >= 1 && matesw_insert(opt, b, n_ma, ma))) {
+            if (incr && settled && n_ma >= 1) ++stat[1];
+            ++n_ma;
+            for (i = 0; i < n_ma - 1; ++i) if (ma[i].score < b.score) break;
+            int tmp = i;
+            for (i = n_ma - 1; i > tmp; --i) ma[i] = ma[i - 1];
+            ma[i] = b;
+            settled = false;
+        }
+        if (n && !(incr && settled)) {
+            ++stat[2];
+            settled = n_ma >= 2;                               // (below two regions the procedure returns at once)
+            n_ma = sort_dedup_patch(ix, opt, S, 0, n_ma, ma, 0, keys);
+        }
     }
     return n;
 }
@@ -388,9 +401,13 @@ __global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPe
         pe_anchors(opt, c, P, n_anch);
         int q = job_first[pi];
         const int q_end = q + job_num[pi];
+        bool settled[2] = { false, false };
+        const bool incr = !(tv.debug & 0x800);
+        int stat[3] = { 0, 0, 0 };                               // rescued regions, of which declined by matesw_insert, full mem_sort_dedup_patch calls
         for (int i = 0; i < 2; ++i)
             for (int j = 0; j < n_anch[i] && j < opt.max_matesw; ++j)
-                matesw(ix, opt, S, P.W, pes, P.anchors[i][j], l_seq[!i], seq[!i], n[!i], a[!i], cap[!i], err, rjobs, rres, q, q_end, i << 16 | j << 2, kbase ? kbase + koff[!i] : nullptr);
+                matesw(ix, opt, S, P.W, pes, P.anchors[i][j], l_seq[!i], seq[!i], n[!i], a[!i], cap[!i], err, rjobs, rres, q, q_end, i << 16 | j << 2, kbase ? kbase + koff[!i] : nullptr, settled[!i], incr, stat);
+        if ((tv.debug & 0x1000) && stat[0] + stat[2]) printf("[k_pe_pair] pair %d: %d + %d regions, %d rescued, %d declined, %d full calls\n", pi, n[0], n[1], stat[0], stat[1], stat[2]);
     }
     n_pri[0] = mark_primary_se(opt, n[0], a[0], (int64_t)(id << 1 | 0), zb[0], kbase ? kbase + koff[0] : nullptr);
     n_pri[1] = mark_primary_se(opt, n[1], a[1], (int64_t)(id << 1 | 1), zb[1], kbase ? kbase + koff[1] : nullptr);

@@ -563,6 +563,108 @@ DEV int sort_dedup_patch(const DevIndex& ix, const MemOpt& opt, PostScratch& S, 
 }
 
 
+// The redundancy test of mem_sort_dedup_patch's inner loop for q before p in end order (the loop's window rule included)
+DEV bool sdp_redundant(const MemOpt& opt, const AlnReg& q, const AlnReg& p)
+{
+    if (p.rid != q.rid || p.rb >= q.re + opt.max_chain_gap) return false;
+    const int64_t orr = q.re - p.rb;
+    const int64_t oq = q.qb < p.qb ? q.qe - p.qb : p.qe - q.qb;
+    const int64_t mr = q.re - q.rb < p.re - p.rb ? q.re - q.rb : p.re - p.rb;
+    const int64_t mq = q.qe - q.qb < p.qe - p.qb ? q.qe - q.qb : p.qe - p.qb;
+    return (float)orr > opt.mask_level_redun * (float)mr && (float)oq > opt.mask_level_redun * (float)mq;
+}
+DEV bool sdp_redundant_with(const MemOpt& opt, const AlnReg& x, const AlnReg& b)      // x from the list against the new region b
+{
+    return x.re < b.re ? sdp_redundant(opt, x, b) : sdp_redundant(opt, b, x);
+}
+
+// mem_matesw calls mem_sort_dedup_patch(query = 0) on the mate's whole hit list after every rescue attempt: sort by end,
+// drop one region of every redundant pair met in that order, sort by (score desc, rb, qb), drop exact duplicates.  A pair in
+// a repeat family does that a hundred times on hundreds of regions.  What a call *returns* is cheap to say once the list
+// has been through one call (`settled`):
+//  * its output is strictly ordered by (score desc, rb, qb) -- two regions with equal (rb, qb) are redundant, and a region
+//    that survives the loop has been tested against every survivor in its window, so no two survivors are redundant (the
+//    test is a property of the pair: for regions with equal ends it comes out the same either way round) -- i.e. the
+//    list between calls is a *set* in canonical order, whatever the unstable sorts did with ties;
+//  * a call on a settled list to which nothing was added changes nothing;
+//  * a call on a settled list plus one new region b only ever fires on pairs that contain b: in end order b first walks
+//    down (it removes every redundant region until one with a higher score removes b), then the regions above b meet it
+//    (a lower-scoring one is removed, the first other one removes b).  Let C be the regions redundant with b.  If b
+//    outscores all of C, C goes and b stays; if all of C outscore b, b goes; both whatever the order.  Otherwise the
+//    order matters and it is the end order, well defined when the ends in C and b are distinct; if they are not (the tie
+//    order of upstream's introsort decides) this function declines and the caller runs the procedure itself.
+// Returns false when it declines (nothing modified).
+DEV bool matesw_insert(const MemOpt& opt, const AlnReg& b, int& n_ma, AlnReg* ma)
+{
+    if (b.qe <= b.qb || b.re <= b.rb) return false;
+    int n_c = 0, hi = -INT_MAX_, lo = INT_MAX_;
+    bool tie_b = false;
+    for (int k = 0; k < n_ma; ++k) {
+        const AlnReg& x = ma[k];
+        if (x.rid != b.rid) continue;
+        if (sdp_redundant_with(opt, x, b)) {
+            ++n_c; hi = hi > x.score ? hi : x.score; lo = lo < x.score ? lo : x.score;
+            tie_b |= x.re == b.re;
+        }
+    }
+    bool b_alive = true;
+    int n_kill = 0;
+    if (n_c == 0) {
+    } else if (b.score > hi) {
+        for (int k = 0; k < n_ma; ++k)
+            if (ma[k].rid == b.rid && sdp_redundant_with(opt, ma[k], b)) { ma[k].qe = ma[k].qb; ++n_kill; }
+    } else if (b.score < lo) {
+        b_alive = false;
+    } else {
+        if (tie_b || n_c > 16) return false;
+        for (int k = 0; k < n_ma; ++k) {                        // two members of C with the same end: their order is the sort's
+            if (ma[k].rid != b.rid || !sdp_redundant_with(opt, ma[k], b)) continue;
+            for (int l = k + 1; l < n_ma; ++l)
+                if (ma[l].re == ma[k].re && ma[l].rid == b.rid && sdp_redundant_with(opt, ma[l], b)) return false;
+        }
+        int64_t cur = b.re;
+        for (;;) {                                              // b's own walk down the end order
+            int best = -1;
+            for (int k = 0; k < n_ma; ++k) {
+                const AlnReg& x = ma[k];
+                if (x.rid != b.rid || x.qe <= x.qb || x.re >= cur || !sdp_redundant(opt, x, b)) continue;
+                if (best < 0 || x.re > ma[best].re) best = k;
+            }
+            if (best < 0) break;
+            if (b.score < ma[best].score) { b_alive = false; break; }
+            cur = ma[best].re; ma[best].qe = ma[best].qb; ++n_kill;
+        }
+        cur = b.re;
+        while (b_alive) {                                       // the regions above b, nearest end first
+            int best = -1;
+            for (int k = 0; k < n_ma; ++k) {
+                const AlnReg& x = ma[k];
+                if (x.rid != b.rid || x.qe <= x.qb || x.re <= cur || !sdp_redundant(opt, b, x)) continue;
+                if (best < 0 || x.re < ma[best].re) best = k;
+            }
+            if (best < 0) break;
+            if (ma[best].score < b.score) { cur = ma[best].re; ma[best].qe = ma[best].qb; ++n_kill; }
+            else b_alive = false;
+        }
+    }
+    int m = n_ma;
+    if (n_kill) {
+        m = 0;
+        for (int k = 0; k < n_ma; ++k)
+            if (ma[k].qe > ma[k].qb) { if (m != k) ma[m] = ma[k]; ++m; }
+    }
+    if (b_alive) {
+        int pos = 0;                                            // canonical place: behind every region that sorts before b
+        while (pos < m && (ma[pos].score > b.score || (ma[pos].score == b.score && (ma[pos].rb < b.rb || (ma[pos].rb == b.rb && ma[pos].qb <= b.qb))))) ++pos;
+        for (int k = m; k > pos; --k) ma[k] = ma[k - 1];
+        ma[pos] = b; ma[pos].n_comp = 1;
+        ++m;
+    }
+    n_ma = m;
+    return true;
+}
+
+
 // The same procedure run by a whole wavefront on one read (k_post1<true>, long reads): every lane follows the control flow
 // (all decisions are read from memory that only lane 0 writes, with a barrier on either side of each write), lane 0 does the
 // updates, and the patch alignments run across the lanes.

@@ -434,3 +434,29 @@ def synth_repeat_genome(total_bp=1500000, n_copies=1200, fam_len=300, div=0.10, 
             c = (3 - c)[::-1]
         g[st:st + fam_len] = c
     return [("chrR", BASES[g].tobytes())], [int(x) for x in starts]
+
+
+def synth_tandem_genome(total_bp=400000, seed=0x7A4D, n_arrays=3, array_bp=30000, mono_len=171, hor=4, div=0.015, n_sine=250):
+    """Repeat structure that makes paired-end finalisation heavy (what centromeric satellites and Alus do on GRCh38): tandem
+    arrays of a `mono_len`-base monomer in `hor`-monomer higher-order repeats (copies `div` diverged), plus a dispersed
+    300-base family.  A pair inside an array has hundreds of hits per end, dozens of rescue anchors, and rescued
+    regions that tie with existing hits in score and end coordinate -- the cases mem_matesw's repeated
+    mem_sort_dedup_patch decides by sort order.  -> (seqs, [(start, end) of the arrays in contig 0])"""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=total_bp, dtype=np.uint8)
+    mono = rng.integers(0, 4, size=mono_len, dtype=np.uint8)
+    unit = np.concatenate([_diverge(rng, mono, 0.2) for _ in range(hor)])
+    arrays = []
+    for k in range(n_arrays):
+        st = 20000 + k * (total_bp - 40000) // n_arrays
+        arr = unit[np.arange(array_bp) % len(unit)]
+        g[st:st + array_bp] = _diverge(rng, arr, div)
+        arrays.append((st, st + array_bp))
+    cons = rng.integers(0, 4, size=300, dtype=np.uint8)
+    for _ in range(n_sine):
+        st = int(rng.integers(1000, total_bp - 1400))
+        if any(a - 400 < st < b for a, b in arrays):
+            continue
+        c = _diverge(rng, cons, 0.10)
+        g[st:st + 300] = (3 - c)[::-1] if rng.random() < 0.5 else c
+    return [("chrT", BASES[g].tobytes())], arrays

@@ -128,3 +128,44 @@ extern "C" int unit_sort_regs(int n, void* regs, int which, int by_key)
     hipFree(d); hipFree(k);
     return rc;
 }
+
+// mem_matesw's maintenance of the mate's hit list (k_pe.hip: matesw), one rescued region after the other: incr == 0 is
+// upstream's sequence (insert behind the regions that score at least as high, then mem_sort_dedup_patch without a query);
+// incr == 1 goes through matesw_insert once the list has been through one such call.  stat: final n, declined, full calls
+__global__ void k_unit_matesw_list(MemOpt opt, AlnReg* ma, int n0, const AlnReg* add, int n_add, int incr, SortKey* keys, int* stat)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    DevIndex ix; memset(&ix, 0, sizeof ix);
+    PostScratch S; memset(&S, 0, sizeof S);
+    int n = n0, declined = 0, full = 0;
+    bool settled = false;
+    for (int k = 0; k < n_add; ++k) {
+        AlnReg b = add[k];
+        if (!(incr && settled && n >= 1 && matesw_insert(opt, b, n, ma))) {
+            if (incr && settled && n >= 1) ++declined;
+            ++n;
+            int i;
+            for (i = 0; i < n - 1; ++i) if (ma[i].score < b.score) break;
+            for (int j = n - 1; j > i; --j) ma[j] = ma[j - 1];
+            ma[i] = b;
+            settled = n >= 2;
+            ++full;
+            n = sort_dedup_patch(ix, opt, S, 0, n, ma, 0, keys);
+        }
+    }
+    stat[0] = n; stat[1] = declined; stat[2] = full;
+}
+extern "C" int unit_matesw_list(const MemOpt* opt, void* regs, int n0, const void* add, int n_add, int incr, int* stat3)
+{
+    AlnReg *d, *da; SortKey* k; int* ds;
+    hipMalloc((void**)&d, (size_t)(n0 + n_add) * sizeof(AlnReg) + 16); hipMalloc((void**)&da, (size_t)n_add * sizeof(AlnReg) + 16);
+    hipMalloc((void**)&k, (size_t)(n0 + n_add) * sizeof(SortKey) + 16); hipMalloc((void**)&ds, 16);
+    hipMemcpy(d, regs, (size_t)n0 * sizeof(AlnReg), hipMemcpyHostToDevice);
+    hipMemcpy(da, add, (size_t)n_add * sizeof(AlnReg), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_unit_matesw_list, dim3(1), dim3(64), 0, 0, *opt, d, n0, (const AlnReg*)da, n_add, incr, k, ds);
+    int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+    hipMemcpy(stat3, ds, 12, hipMemcpyDeviceToHost);
+    hipMemcpy(regs, d, (size_t)(n0 + n_add) * sizeof(AlnReg), hipMemcpyDeviceToHost);
+    hipFree(d); hipFree(da); hipFree(k); hipFree(ds);
+    return rc;
+}

@@ -208,3 +208,70 @@ def test_units_emu_sort_regs():
 @pytest.mark.gpu
 def test_units_gpu_sort_regs():
     _check_sort_regs(_load("hip"), 150, 3000)
+
+
+REG_DTYPE = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("rid", "<i4"), ("score", "<i4"), ("truesc", "<i4"), ("sub", "<i4"),
+                      ("alt_sc", "<i4"), ("csub", "<i4"), ("sub_n", "<i4"), ("w", "<i4"), ("seedcov", "<i4"), ("secondary", "<i4"),
+                      ("secondary_all", "<i4"), ("seedlen0", "<i4"), ("n_comp", "<i4"), ("is_alt", "<i4"), ("frac_rep", "<f4"), ("pad_", "<i4"), ("hash", "<u8")])
+
+
+def _tandem_regions(rng, n, tie_level):
+    """hit lists the way a mate inside a tandem array carries them: clusters of near-identical regions (same or neighbouring
+    copy of the period, same or shifted stretch of the read), scores from a narrow range, many shared end coordinates"""
+    a = np.zeros(n, dtype=REG_DTYPE)
+    period = int(rng.choice([171, 50, 684]))
+    n_clu = max(1, n // int(rng.choice([1, 2, 4])))
+    c_rb = 100000 + period * rng.integers(0, max(2, n_clu // 2), size=n_clu) + rng.integers(0, 3, size=n_clu) * (tie_level < 2)
+    c_len = rng.integers(40, 101, size=n_clu)
+    c_qb = np.where(rng.random(n_clu) < 0.5, 0, rng.integers(0, 60, size=n_clu))
+    k = rng.integers(0, n_clu, size=n)
+    jit = (lambda: rng.integers(-2, 3, size=n) * (rng.random(n) < (0.1, 0.4, 0.8)[tie_level]))
+    ln = np.maximum(20, c_len[k] + jit())
+    a["rb"] = c_rb[k] + jit(); a["re"] = a["rb"] + ln + jit() * (rng.random(n) < 0.2)
+    a["qb"] = np.maximum(0, c_qb[k] + jit()); a["qe"] = a["qb"] + ln
+    a["rid"] = (rng.random(n) < 0.03).astype(np.int32)
+    a["rb"] += 50000000 * a["rid"]; a["re"] += 50000000 * a["rid"]             # (a contig is a stretch of the coordinate axis)
+    a["score"] = ln - 5 * rng.integers(0, (2, 3, 6)[tie_level], size=n)
+    a["truesc"] = a["score"]; a["csub"] = rng.integers(0, 60, size=n); a["seedcov"] = ln // 2; a["secondary"] = -1
+    a["n_comp"] = rng.integers(0, 4, size=n); a["w"] = rng.integers(0, 100, size=n)
+    a["pad_"] = np.arange(n)                                                  # identity of the record: which of two twins survives shows
+    return a
+
+
+def _check_matesw_list(units, n_cases, max_n0, max_add):
+    """the mate's hit list after a sequence of rescued regions: matesw_insert (post_common.h) must leave exactly the records
+    upstream's insert + mem_sort_dedup_patch leaves, in the same order"""
+    assert units.unit_sizeof_alnreg() == REG_DTYPE.itemsize == 96
+    units.unit_matesw_list.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    orc = B.oracle_lib()
+    rng = np.random.default_rng(77)
+    fast = slow = 0
+    for it in range(n_cases):
+        n0 = int(rng.integers(0, max_n0)) if it else max_n0                    # the first case is the largest
+        n_add = int(rng.integers(1, max_add))
+        tie_level = it % 3
+        both = _tandem_regions(rng, n0 + n_add, tie_level)
+        sel = rng.permutation(n0 + n_add)
+        a0, add = both[sel[:n0]].copy(), both[sel[n0:]].copy()
+        opts = B.set_opt(bytearray(orc.default_options()), max_chain_gap=int(rng.choice([10000, 10000, 100])), mask_level_redun=float(rng.choice([0.95, 0.95, 0.5])))
+        ob = ctypes.create_string_buffer(bytes(opts), 168)
+        res = []
+        for incr in (0, 1):
+            buf = np.zeros(n0 + n_add, dtype=REG_DTYPE); buf[:n0] = a0
+            stat = (ctypes.c_int * 3)()
+            assert units.unit_matesw_list(ob, buf.ctypes.data, n0, add.ctypes.data, n_add, incr, stat) == 0
+            res.append((stat[0], buf[:stat[0]].tobytes(), stat[1], stat[2]))
+        assert res[0][0] == res[1][0] and res[0][1] == res[1][1], (it, n0, n_add, tie_level, res[0][0], res[1][0])
+        assert res[0][3] == n_add
+        fast += n_add - res[1][3]; slow += res[1][3]
+    assert fast > 4 * slow, (fast, slow)                                       # the short cut is what normally runs
+    return fast, slow
+
+
+def test_units_emu_matesw_list():
+    _check_matesw_list(_load("emu"), 40, 400, 60)
+
+
+@pytest.mark.gpu
+def test_units_gpu_matesw_list():
+    _check_matesw_list(_load("hip"), 120, 2500, 150)
