@@ -317,6 +317,7 @@ def parse_args():
                     "proper-pair statistics) instead of inferred per call; the call is then a single pass over the tiles")
     ap.add_argument("--keep-image", default=None, help="also copy the index image to this path (profiling helper)")
     ap.add_argument("--dump-request", default=None, help="write the first --cpu-sample reads as a request file (profiling helper)")
+    ap.add_argument("--dump-only", action="store_true", help="with --keep-image / --dump-request: stop once the files are written (profiling helper for the torch-free driver)")
     ap.add_argument("--image", default=os.environ.get("BWAHIP_REF_IMG"), help="use an existing .img (e.g. GATK's Homo_sapiens_assembly38.fasta.img) instead of "
                     "the synthetic genome; reads are sampled from its packed reference (default: $BWAHIP_REF_IMG)")
     args = ap.parse_args()
@@ -467,6 +468,11 @@ def main():
         S0 = min(max(args.cpu_sample, 1), R)
         with open(args.dump_request, "wb") as f:
             f.write(struct.pack("<i", S0)); f.write(payload[:S0].cpu().numpy().tobytes())
+    if args.dump_only:
+        lib.jnibwa_destroyIndex(idx)
+        if own_image and rank == 0:
+            os.unlink(img)
+        return
     h_off = (np.arange(R + 1, dtype=np.int64) * (L + 1))
     torch.cuda.synchronize()
     batch = lib.bwamem_hip_batch_wrap_device(idx, payload.data_ptr(), R * (L + 1), R, h_off.ctypes.data)

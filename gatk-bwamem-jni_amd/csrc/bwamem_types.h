@@ -114,6 +114,7 @@ struct KswR { int score, te, qe, score2, te2, tb, qb; };
 // per-kernel algorithmic counters; accumulated with one atomic per wave
 struct DevCounters {
     unsigned long long n_ext, n_lf, n_sa, n_dp_cells, n_ref_bases, n_reads;
+    unsigned long long dbg[10];      // BWAMEM_HIP_DEBUGK bit 0x2000: shader clocks per phase of the lane-per-pair kernels, summed over waves (printed per tile)
 };
 
 // per-tile error / overflow flags set by kernels, read back by the host after each stage

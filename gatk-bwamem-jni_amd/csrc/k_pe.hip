@@ -297,6 +297,13 @@ DEV void pe_anchors(const MemOpt& opt, const PeCtx& c, PeScratch& P, int n_anch[
     }
 }
 
+// Pairs whose ends carry many regions (reads in repeat families) get a wavefront each for the list work of mate rescue --
+// which orientations an anchor's window already holds a hit for, where a rescued region goes, what it displaces: all of it
+// linear in the mate's list and repeated per anchor -- instead of one lane (k_pe_rescue_plan_wave, k_pe_matesw_wave).
+#define PE_HEAVY_MIN 32
+#define PE_WAVE_MAX_ANCHORS 128
+DEV bool pe_heavy(const MemOpt& opt, int debug, int n0, int n1) { return n0 + n1 >= PE_HEAVY_MIN && n0 > 0 && n1 > 0 && opt.max_matesw <= PE_WAVE_MAX_ANCHORS && !(debug & 0x4000); }
+
 // mate rescue, step 1 (one lane per pair): list the alignments the rescue of this pair may ask for
 __global__ void k_pe_rescue_plan(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3,
                                  RescueJob* jobs, int32_t* job_first, int32_t* job_num, int32_t* counter, int cap)
@@ -305,7 +312,9 @@ __global__ void k_pe_rescue_plan(DevIndex ix, MemOpt opt, TileView tv, PeView pv
     if (pi >= tv.n_reads >> 1) return;
     const MemPestat pes[4] = { p0, p1, p2, p3 };
     PeCtx c = pe_ctx(tv, pv, pi);
+    if (pe_heavy(opt, tv.debug, c.n[0], c.n[1])) return;       // k_pe_rescue_plan_wave's
     PeScratch P = pe_scratch(opt, pv, pi);
+    const long long t0 = (tv.debug & 0x2000) ? clock64() : 0;
     int n_anch[2];
     pe_anchors(opt, c, P, n_anch);
     int first = 0, cnt = 0;
@@ -337,6 +346,74 @@ __global__ void k_pe_rescue_plan(DevIndex ix, MemOpt opt, TileView tv, PeView pv
         }
     }
     job_first[pi] = first; job_num[pi] = cnt;
+    if ((tv.debug & 0x2000) && __ffsll((long long)__ballot(1)) - 1 == (int)(threadIdx.x & 63)) atomicAdd(&tv.cnt->dbg[4], (unsigned long long)(clock64() - t0));
+}
+
+// rescue_skip by the wavefront: bit r set = orientation r needs no rescue
+DEV int rescue_skip_wave(const DevIndex& ix, const MemPestat* pes, const AlnReg& a, int n_ma, const AlnReg* ma, int lane)
+{
+    int m = 0, mine = 0;
+    for (int r = 0; r < 4; ++r) m |= pes[r].failed ? 1 << r : 0;
+    for (int k = lane; k < n_ma; k += 64) {
+        int64_t dist;
+        const int r = infer_dir(ix.l_pac, a.rb, ma[k].rb, &dist);
+        if (dist >= pes[r].low && dist <= pes[r].high) mine |= 1 << r;
+    }
+    for (int r = 0; r < 4; ++r) if (__ballot(mine >> r & 1)) m |= 1 << r;
+    return m;
+}
+
+// mate rescue, step 1 for a heavy pair: one wavefront (workgroup) per pair; light pairs return at once
+__global__ void __launch_bounds__(64) k_pe_rescue_plan_wave(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3,
+                                                            RescueJob* jobs, int32_t* job_first, int32_t* job_num, int32_t* counter, int cap)
+{
+    __shared__ uint8_t skip_s[2 * PE_WAVE_MAX_ANCHORS];
+    const int pi = blockIdx.x, lane = threadIdx.x;
+    PeCtx c = pe_ctx(tv, pv, pi);
+    if (!pe_heavy(opt, tv.debug, c.n[0], c.n[1])) return;
+    const MemPestat pes[4] = { p0, p1, p2, p3 };
+    PeScratch P = pe_scratch(opt, pv, pi);
+    int n_anch[2] = { 0, 0 };
+    if (lane == 0) pe_anchors(opt, c, P, n_anch);
+    for (int i = 0; i < 2; ++i) { n_anch[i] = __shfl(n_anch[i], 0); n_anch[i] = n_anch[i] < opt.max_matesw ? n_anch[i] : opt.max_matesw; }
+    __syncthreads();
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < n_anch[i]; ++j) {
+            const int m = rescue_skip_wave(ix, pes, P.anchors[i][j], c.n[!i], c.a[!i], lane);
+            if (lane == 0) skip_s[i * PE_WAVE_MAX_ANCHORS + j] = (uint8_t)m;
+        }
+    __syncthreads();
+    const int n_combo = 4 * (n_anch[0] + n_anch[1]);
+    int first = 0, cnt = 0;
+    for (int pass = 0; pass < 2; ++pass) {                      // count, reserve, write (in tag order: end, anchor, orientation)
+        int k = 0;
+        for (int c0 = 0; c0 < n_combo; c0 += 64) {
+            const int cc = c0 + lane;
+            bool ok = false;
+            RescueJob jb;
+            if (cc < n_combo) {
+                const int ai = cc >> 2, r = cc & 3, i = ai >= n_anch[0] ? 1 : 0, j = ai - (i ? n_anch[0] : 0);
+                if (!(skip_s[i * PE_WAVE_MAX_ANCHORS + j] >> r & 1)) {
+                    int is_rev, xtra; int64_t rb, re;
+                    ok = rescue_req(ix, opt, pes, P.anchors[i][j], r, c.l_seq[!i], rb, re, is_rev, xtra);
+                    jb.rb = rb; jb.read = c.rd[!i]; jb.tag = i << 16 | j << 2 | r; jb.l_ms = c.l_seq[!i]; jb.is_rev = is_rev; jb.tlen = (int)(re - rb); jb.xtra = xtra; jb.q_off = 0; jb.pad_ = 0;
+                }
+            }
+            const uint64_t bal = __ballot(ok);
+            if (pass == 1 && ok && cnt > 0) jobs[first + k + __popcll(bal & ((1ull << lane) - 1))] = jb;
+            k += __popcll(bal);
+        }
+        if (pass == 0) {
+            cnt = k;
+            if (cnt > 0) {
+                if (lane == 0) first = atomicAdd(counter, cnt);
+                first = __shfl(first, 0);
+                if (first + cnt > cap) { if (lane == 0) atomicOr(tv.err, ERR_RESCUE_CAP); cnt = 0; }
+            }
+            if (cnt == 0) break;
+        }
+    }
+    if (lane == 0) { job_first[pi] = first; job_num[pi] = cnt; }
 }
 
 // mate rescue, step 2: ksw_align2 for the listed alignments, four per wavefront (one per 16-lane group, sw_common.h).
@@ -368,6 +445,98 @@ __global__ void __launch_bounds__(64) k_pe_rescue_sw(DevIndex ix, MemOpt opt, Ti
     if (err) atomicOr(tv.err, err);
 }
 
+// mem_matesw for one anchor of a heavy pair, by the wavefront (uniform arguments; see matesw)
+DEV void matesw_wave(const DevIndex& ix, const MemOpt& opt, SwScratch& W, const MemPestat* pes, const AlnReg& a,
+                     int l_ms, const uint8_t* ms, int& n_ma, AlnReg* ma, int cap_ma, int& err,
+                     const RescueJob* jobs, const KswR* results, int& q, int q_end, int tag0, SortKey* keys, bool& settled, int lane)
+{
+    const int64_t l_pac = ix.l_pac;
+    const int skip = rescue_skip_wave(ix, pes, a, n_ma, ma, lane);
+    if (skip == 15) return;
+    int n = 0;
+    for (int r = 0; r < 4; ++r) {
+        if (skip >> r & 1) continue;
+        int is_rev, xtra;
+        int64_t rb, re;
+        bool ins = false;
+        AlnReg b;
+        if (rescue_req(ix, opt, pes, a, r, l_ms, rb, re, is_rev, xtra)) {
+            KswR aln; aln.score = RESCUE_NOT_RUN; aln.te = aln.qe = aln.score2 = aln.te2 = aln.tb = aln.qb = 0;
+            while (q < q_end && jobs[q].tag < (tag0 | r)) ++q;
+            if (q < q_end && jobs[q].tag == (tag0 | r)) aln = results[q];
+            if (aln.score == RESCUE_NOT_RUN) {                 // a mate too long for the wave kernel: one lane's scalar kernel
+                int e = 0;
+                if (lane == 0) { SwIn I; I.ms = ms; I.l_ms = l_ms; I.is_rev = is_rev; I.qrev = 0; I.t0 = rb; I.trev = 0; aln = sw_align2(ix, opt, I, l_ms, (int)(re - rb), xtra, W, e); }
+                aln.score = __shfl(aln.score, 0); aln.te = __shfl(aln.te, 0); aln.qe = __shfl(aln.qe, 0); aln.score2 = __shfl(aln.score2, 0);
+                aln.te2 = __shfl(aln.te2, 0); aln.tb = __shfl(aln.tb, 0); aln.qb = __shfl(aln.qb, 0);
+                err |= __shfl(e, 0);
+            }
+            if (aln.score >= opt.min_seed_len && aln.qb >= 0) {
+                b.rb = b.re = 0; b.qb = b.qe = 0; b.rid = 0; b.score = b.truesc = b.sub = b.alt_sc = b.csub = b.sub_n = b.w = b.seedcov = 0;
+                b.secondary = b.secondary_all = b.seedlen0 = b.n_comp = b.is_alt = 0; b.frac_rep = 0.f; b.pad_ = 0; b.hash = 0;
+                b.rid = a.rid;
+                b.is_alt = a.is_alt;
+                b.qb = is_rev ? l_ms - (aln.qe + 1) : aln.qb;
+                b.qe = is_rev ? l_ms - aln.qb : aln.qe + 1;
+                b.rb = is_rev ? (l_pac << 1) - (rb + aln.te + 1) : rb + aln.tb;
+                b.re = is_rev ? (l_pac << 1) - (rb + aln.tb) : rb + aln.te + 1;
+                b.score = aln.score;
+                b.csub = aln.score2;
+                b.secondary = -1;
+                b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+                if (n_ma >= cap_ma) { err |= ERR_SCRATCH; return; }
+                ins = true;
+            }
+            ++n;
+        }
+        if (ins && !(settled && n_ma >= 1 && matesw_insert_wave(opt, b, n_ma, ma, lane))) {
+            int pos = n_ma;                                     // in front of the first region that scores lower
+            for (int base = 0; base < n_ma; base += 64) {
+                const int k = base + lane;
+                const uint64_t lower = __ballot(k < n_ma && ma[k].score < b.score);
+                if (lower) { pos = base + __ffsll((long long)lower) - 1; break; }
+            }
+            regs_insert_wave(ma, n_ma, pos, b, lane);
+            ++n_ma;
+            settled = false;
+        }
+        if (n && !settled) {
+            settled = n_ma >= 2;
+            n_ma = sort_dedup_nq_wave(opt, n_ma, ma, keys, lane);
+        }
+    }
+}
+
+// mate rescue, step 3 for the heavy pairs: one wavefront per pair replays upstream's sequence on both ends' lists and leaves
+// the new region counts; k_pe_pair then finds job_num < 0 and goes straight on to primary marking
+__global__ void __launch_bounds__(64) k_pe_matesw_wave(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3,
+                                                       const RescueJob* rjobs, const KswR* rres, const int32_t* job_first, int32_t* job_num)
+{
+    const int pi = blockIdx.x, lane = threadIdx.x;
+    if (tv.err[0] & ERR_RESCUE_CAP) return;
+    PeCtx c = pe_ctx(tv, pv, pi);
+    if (!pe_heavy(opt, tv.debug, c.n[0], c.n[1])) return;
+    const MemPestat pes[4] = { p0, p1, p2, p3 };
+    PeScratch P = pe_scratch(opt, pv, pi);
+    SortKey* const kbase = pv.keys && !(tv.debug & 0x400) ? (SortKey*)pv.keys : nullptr;
+    int n_anch[2] = { 0, 0 };
+    if (lane == 0) pe_anchors(opt, c, P, n_anch);
+    for (int i = 0; i < 2; ++i) n_anch[i] = __shfl(n_anch[i], 0);
+    __syncthreads();
+    int err = 0, q = job_first[pi];
+    const int q_end = q + job_num[pi];
+    bool settled[2] = { false, false };
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < n_anch[i] && j < opt.max_matesw; ++j)
+            matesw_wave(ix, opt, P.W, pes, P.anchors[i][j], c.l_seq[!i], c.seq[!i], c.n[!i], c.a[!i], c.cap[!i], err, rjobs, rres, q, q_end, i << 16 | j << 2,
+                        kbase ? kbase + pv.reg_off[c.rd[!i]] : nullptr, settled[!i], lane);
+    if (lane == 0) {
+        pv.n_regs[c.rd[0]] = c.n[0]; pv.n_regs[c.rd[1]] = c.n[1];
+        job_num[pi] = -1;
+        if (err) atomicOr(tv.err, err);
+    }
+}
+
 // mem_sam_pe, first half (one lane per pair): mate rescue (step 3: upstream's sequence with the alignments precomputed),
 // primary marking, pairing and the mapping-quality decisions.
 // Regions whose CIGAR needs a banded global alignment are then listed as jobs for k_gcigar_lane / k_gcigar (those the record
@@ -396,7 +565,10 @@ __global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPe
     const int64_t koff[2] = { pv.reg_off[rd[0]], pv.reg_off[rd[1]] };
     const uint64_t id = (uint64_t)((tv.read_id0 >> 1) + pi);
     int z[2] = { 0, 0 }, o = 0, subo = 0, n_sub = 0, extra_flag = 1, n_pri[2], q_se[2] = { 0, 0 };
-    if (!(opt.flag & MEM_F_NO_RESCUE)) {                       // mate rescue from the best hits of each end
+    const bool clk = (tv.debug & 0x2000) != 0;
+    long long t_prev = clk ? clock64() : 0;
+#define PE_CLK(k) do { if (clk) { const long long t_ = clock64(); if (__ffsll((long long)__ballot(1)) - 1 == (int)(threadIdx.x & 63)) atomicAdd(&tv.cnt->dbg[k], (unsigned long long)(t_ - t_prev)); t_prev = t_; } } while (0)
+    if (!(opt.flag & MEM_F_NO_RESCUE) && job_num[pi] >= 0) {  // mate rescue from the best hits of each end (< 0: done by k_pe_matesw_wave)
         int n_anch[2];
         pe_anchors(opt, c, P, n_anch);
         int q = job_first[pi];
@@ -409,10 +581,12 @@ __global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPe
                 matesw(ix, opt, S, P.W, pes, P.anchors[i][j], l_seq[!i], seq[!i], n[!i], a[!i], cap[!i], err, rjobs, rres, q, q_end, i << 16 | j << 2, kbase ? kbase + koff[!i] : nullptr, settled[!i], incr, stat);
         if ((tv.debug & 0x1000) && stat[0] + stat[2]) printf("[k_pe_pair] pair %d: %d + %d regions, %d rescued, %d declined, %d full calls\n", pi, n[0], n[1], stat[0], stat[1], stat[2]);
     }
+    PE_CLK(0);
     n_pri[0] = mark_primary_se(opt, n[0], a[0], (int64_t)(id << 1 | 0), zb[0], kbase ? kbase + koff[0] : nullptr);
     n_pri[1] = mark_primary_se(opt, n[1], a[1], (int64_t)(id << 1 | 1), zb[1], kbase ? kbase + koff[1] : nullptr);
     if (opt.flag & MEM_F_PRIMARY5) { reorder_primary5(opt.T, n[0], a[0]); reorder_primary5(opt.T, n[1], a[1]); }
 
+    PE_CLK(1);
     bool paired = false;
     if (!(opt.flag & MEM_F_NOPAIRING) && n_pri[0] && n_pri[1]
         && (o = mem_pair(ix, opt, pes, pv.ptab, a[0], a[1], (int)id, &subo, &n_sub, z, n_pri, v, u, cap_u, err)) > 0) {
@@ -461,6 +635,7 @@ __global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPe
             }
         }
     }
+    PE_CLK(2);
     PeState st; st.paired = paired; st.z0 = z[0]; st.z1 = z[1]; st.n_pri0 = n_pri[0]; st.n_pri1 = n_pri[1]; st.extra_flag = extra_flag; st.q_se0 = q_se[0]; st.q_se1 = q_se[1];
     states[pi] = st;
     // Global-alignment jobs: the regions the record stage will turn into a record, an XA entry or a mate summary and whose
@@ -500,6 +675,8 @@ __global__ void k_pe_pair(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPe
             }
         }
     }
+    PE_CLK(3);
+#undef PE_CLK
     if (S.err | err) atomicOr(tv.err, S.err | err);
 }
 
@@ -652,7 +829,11 @@ void launch_pe_pair(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const
     if (!(opt.flag & MEM_F_NO_RESCUE)) {
         hipLaunchKernelGGL(k_pe_rescue_plan, dim3((np + 127) / 128), dim3(128), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3],
                            (RescueJob*)rescue_jobs, rescue_first, rescue_num, rescue_cnt, rescue_cap);
+        hipLaunchKernelGGL(k_pe_rescue_plan_wave, dim3(np), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3],
+                           (RescueJob*)rescue_jobs, rescue_first, rescue_num, rescue_cnt, rescue_cap);
         launch_sw_jobs(st, ix, opt, tv, rescue_jobs, rescue_cnt, rescue_cap, rescue_res, cap_b, tv.max_len);
+        hipLaunchKernelGGL(k_pe_matesw_wave, dim3(np), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3],
+                           (const RescueJob*)rescue_jobs, (const KswR*)rescue_res, (const int32_t*)rescue_first, rescue_num);
     }
     hipLaunchKernelGGL(k_pe_pair, dim3((np + 63) / 64), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3], (PeState*)states,
                        (const RescueJob*)rescue_jobs, (const KswR*)rescue_res, (const int32_t*)rescue_first, (const int32_t*)rescue_num);

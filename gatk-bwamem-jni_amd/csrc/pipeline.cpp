@@ -1200,6 +1200,7 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
             tv = t2;
         }
         PE_OK(hipMemsetAsync(ws.job_cnt.p, 0, 64, ws.stream));
+        if (tv.debug & 0x2000) PE_OK(hipMemsetAsync(ws.cnt.p, 0, sizeof(DevCounters), ws.stream));
         {   // rescue alignments: a few per cent of the pairs ask for one, pairs in repeats for many
             static const int floor0 = []{ const char* e = getenv("BWAMEM_HIP_PE_RESCUE_CAP0"); return e && atoi(e) > 0 ? atoi(e) : 4096; }();   // test knob: start small, take the resize path
             const int rc = std::max(pe_rescue_cap, floor0 < 4096 ? floor0 : std::max(4096, T / 8));
@@ -1215,6 +1216,12 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
         PE_OK(hipMemcpyAsync(&err, tv.err, 4, hipMemcpyDeviceToHost, ws.stream));
         PE_OK(hipMemcpyAsync(&n_rescue, ws.pe_rescue[2].p, 4, hipMemcpyDeviceToHost, ws.stream));
         PE_OK(hipStreamSynchronize(ws.stream));
+        if (tv.debug & 0x2000) {
+            DevCounters hc;
+            PE_OK(hipMemcpy(&hc, tv.cnt, sizeof hc, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[bwamem_hip] pairing stage, Mclk summed over waves: rescue %.1f mark_primary %.1f pair %.1f jobs %.1f | plan %.1f | rescue jobs %d\n",
+                    hc.dbg[0] / 1e6, hc.dbg[1] / 1e6, hc.dbg[2] / 1e6, hc.dbg[3] / 1e6, hc.dbg[4] / 1e6, n_rescue);
+        }
         if (n_rescue > pe_rescue_cap) { pe_rescue_cap = n_rescue + n_rescue / 4; continue; }     // (the kernels after the plan saw ERR_RESCUE_CAP and did nothing)
         ix->hints.learn_pe(T, n_rescue, n_jobs, cap_u);
         if ((err & ERR_JOB_CAP) || n_jobs > ws.job_cap) { pe_job_cap = std::max(n_jobs + n_jobs / 4, ws.job_cap * 2); continue; }

@@ -665,6 +665,143 @@ DEV bool matesw_insert(const MemOpt& opt, const AlnReg& b, int& n_ma, AlnReg* ma
 }
 
 
+// ---- the same for a pair with hundreds of regions, by the whole wavefront (k_pe.hip: k_pe_matesw_wave).  Called by all 64
+// lanes of a one-wave workgroup with uniform arguments; the list is in global memory, so a barrier stands between a lane's
+// stores and another lane's loads of the same record.
+DEV bool reg_sorts_before(const AlnReg& x, const AlnReg& b)       // x stays in front of b in (score desc, rb, qb) order
+{
+    return x.score > b.score || (x.score == b.score && (x.rb < b.rb || (x.rb == b.rb && x.qb <= b.qb)));
+}
+// open a slot at pos in a[0 .. m) (records move up by one, 64 at a time from the top) and put b there
+DEV void regs_insert_wave(AlnReg* a, int m, int pos, const AlnReg& b, int lane)
+{
+    for (int top = m; top > pos; top -= 64) {
+        const int lo = top - 64 > pos ? top - 64 : pos, k = lo + lane;
+        AlnReg v;
+        if (k < top) v = a[k];
+        __syncthreads();
+        if (k < top) a[k + 1] = v;
+    }
+    __syncthreads();
+    if (lane == 0) a[pos] = b;
+    __syncthreads();
+}
+// drop the records whose bit is set in the lanes' marks (record 64 c + lane <-> bit c of that lane's mask); returns the new count
+DEV int regs_remove_wave(AlnReg* a, int n, uint64_t marks, int lane)
+{
+    int m = 0;
+    for (int base = 0, c = 0; base < n; base += 64, ++c) {
+        const int k = base + lane;
+        const bool keep = k < n && !(marks >> c & 1);
+        const uint64_t bal = __ballot(keep);
+        const int cnt = __popcll(bal);
+        if (m != base || cnt != (n - base < 64 ? n - base : 64)) {          // (nothing above has gone yet: the records stay where they are)
+            AlnReg v;
+            if (keep) v = a[k];
+            __syncthreads();
+            if (keep) a[m + __popcll(bal & ((1ull << lane) - 1))] = v;
+        }
+        m += cnt;
+    }
+    __syncthreads();
+    return m;
+}
+DEV bool matesw_insert_wave(const MemOpt& opt, const AlnReg& b, int& n_ma, AlnReg* ma, int lane)
+{
+    if (b.qe <= b.qb || b.re <= b.rb || n_ma > 4096) return false;
+    uint64_t mine = 0;                                              // this lane's members of C, one bit per 64-record chunk
+    int n_c = 0, hi = -INT_MAX_, lo = INT_MAX_, front_c = 0, front_nc = 0;
+    for (int base = 0, c = 0; base < n_ma; base += 64, ++c) {
+        const int k = base + lane;
+        bool red = false, front = false;
+        if (k < n_ma) {
+            const AlnReg& x = ma[k];
+            red = x.rid == b.rid && sdp_redundant_with(opt, x, b);
+            front = reg_sorts_before(x, b);
+            if (red) { mine |= 1ull << c; hi = hi > x.score ? hi : x.score; lo = lo < x.score ? lo : x.score; }
+        }
+        n_c += __popcll(__ballot(red));
+        front_c += __popcll(__ballot(red && front));
+        front_nc += __popcll(__ballot(!red && front));
+    }
+    if (n_c) { hi = wave_max(hi); lo = -wave_max(-lo); }
+    if (n_c && !(b.score > hi) && !(b.score < lo)) {               // the order of C decides: rare, one lane walks it
+        int ok = 0, m = n_ma;
+        __syncthreads();
+        if (lane == 0) ok = matesw_insert(opt, b, m, ma) ? 1 : 0;
+        ok = __shfl(ok, 0); m = __shfl(m, 0);
+        __syncthreads();
+        if (ok) n_ma = m;
+        return ok != 0;
+    }
+    if (n_c && b.score < lo) return true;                           // b goes, the list stays
+    int m = n_ma, pos = front_nc + front_c;
+    if (n_c) { m = regs_remove_wave(ma, n_ma, mine, lane); pos = front_nc; }
+    AlnReg bb = b; bb.n_comp = 1;
+    regs_insert_wave(ma, m, pos, bb, lane);
+    n_ma = m + 1;
+    return true;
+}
+
+// mem_sort_dedup_patch without a query, by the wavefront: the two sorts on lane 0 (upstream's introsort, whose tie order is
+// part of the result), the overlap loop 64 regions of p's window per step -- p is not modified while it walks (no patching), so
+// "every redundant region goes until one outscores p" is a ballot --, the compactions by prefix counts
+DEV int sort_dedup_nq_wave(const MemOpt& opt, int n, AlnReg* a, SortKey* keys, int lane)
+{
+    if (n <= 1) return n;
+    __syncthreads();
+    if (lane == 0) sort_regs(n, a, keys, RegReLt());
+    __syncthreads();
+    for (int k = lane; k < n; k += 64) a[k].n_comp = 1;
+    __syncthreads();
+    for (int i = 1; i < n; ++i) {
+        const AlnReg& p = a[i];
+        const int64_t p_rb = p.rb, p_re = p.re; const int p_qb = p.qb, p_qe = p.qe, p_rid = p.rid, p_score = p.score;
+        bool p_dead = false, any = false;
+        for (int j0 = i - 1; j0 >= 0; j0 -= 64) {
+            const int j = j0 - lane;
+            bool inwin = false, red = false, kills_p = false;
+            if (j >= 0) {
+                const AlnReg& q = a[j];
+                const int64_t q_rb = q.rb, q_re = q.re; const int q_qb = q.qb, q_qe = q.qe;
+                inwin = q.rid == p_rid && p_rb < q_re + opt.max_chain_gap;
+                if (inwin && q_qe != q_qb) {
+                    const int64_t orr = q_re - p_rb, oq = q_qb < p_qb ? q_qe - p_qb : p_qe - q_qb;
+                    const int64_t mr = q_re - q_rb < p_re - p_rb ? q_re - q_rb : p_re - p_rb, mq = q_qe - q_qb < p_qe - p_qb ? q_qe - q_qb : p_qe - p_qb;
+                    red = (float)orr > opt.mask_level_redun * (float)mr && (float)oq > opt.mask_level_redun * (float)mq;
+                    kills_p = red && p_score < q.score;
+                }
+            }
+            const uint64_t out = __ballot(!inwin);                  // (lanes below record 0 count as outside)
+            uint64_t live = out ? ((1ull << (__ffsll((long long)out) - 1)) - 1) : ~0ull;   // the lanes the walk reaches
+            const uint64_t kp = __ballot(kills_p) & live;
+            if (kp) { live &= (1ull << (__ffsll((long long)kp) - 1)) - 1; p_dead = true; }
+            if (red && (live >> lane & 1)) { a[j].qe = a[j].qb; }
+            any |= (__ballot(red) & live) != 0;
+            if (out || p_dead) break;
+        }
+        if (p_dead && lane == 0) a[i].qe = a[i].qb;
+        if (any || p_dead) __syncthreads();
+    }
+    __syncthreads();
+    uint64_t marks = 0;
+    for (int base = 0, c = 0; base < n; base += 64, ++c) { const int k = base + lane; if (k < n && !(a[k].qe > a[k].qb)) marks |= 1ull << c; }
+    int m = n;
+    if (n <= 4096) m = regs_remove_wave(a, n, marks, lane);
+    else { if (lane == 0) { m = 0; for (int k = 0; k < n; ++k) if (a[k].qe > a[k].qb) { if (m != k) a[m] = a[k]; ++m; } } m = __shfl(m, 0); __syncthreads(); }
+    n = m;
+    if (lane == 0) {
+        sort_regs(n, a, keys, RegSLt());
+        for (int k = 1; k < n; ++k)
+            if (a[k].score == a[k - 1].score && a[k].rb == a[k - 1].rb && a[k].qb == a[k - 1].qb) a[k].qe = a[k].qb;
+        int k; for (k = 1, m = n < 1 ? n : 1; k < n; ++k)
+            if (a[k].qe > a[k].qb) { if (m != k) a[m++] = a[k]; else ++m; }
+    }
+    m = __shfl(m, 0);
+    __syncthreads();
+    return m;
+}
+
 // The same procedure run by a whole wavefront on one read (k_post1<true>, long reads): every lane follows the control flow
 // (all decisions are read from memory that only lane 0 writes, with a barrier on either side of each write), lane 0 does the
 // updates, and the patch alignments run across the lanes.

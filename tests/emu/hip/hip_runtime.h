@@ -77,6 +77,7 @@ static inline unsigned long long __ballot(int pred)
     return m;
 }
 static inline void __syncthreads() { emu::sync_block(); }
+static inline long long clock64() { return 0; }
 
 // DPP subset used by wave_ops.h (gfx9 controls quad_perm, row_shl:n, row_shr:n, wave_shl/shr:1, row_mirror, row_half_mirror,
 // row_bcast:15, row_bcast:31).  Controls that stay inside a 16-lane row rendezvous only the lanes of that row, so that the

@@ -132,6 +132,31 @@ extern "C" int unit_sort_regs(int n, void* regs, int which, int by_key)
 // mem_matesw's maintenance of the mate's hit list (k_pe.hip: matesw), one rescued region after the other: incr == 0 is
 // upstream's sequence (insert behind the regions that score at least as high, then mem_sort_dedup_patch without a query);
 // incr == 1 goes through matesw_insert once the list has been through one such call.  stat: final n, declined, full calls
+// incr == 2: the wavefront forms (matesw_insert_wave, regs_insert_wave, sort_dedup_nq_wave), all 64 lanes
+__global__ void __launch_bounds__(64) k_unit_matesw_list_wave(MemOpt opt, AlnReg* ma, int n0, const AlnReg* add, int n_add, SortKey* keys, int* stat)
+{
+    const int lane = threadIdx.x;
+    int n = n0, declined = 0, full = 0;
+    bool settled = false;
+    for (int k = 0; k < n_add; ++k) {
+        const AlnReg b = add[k];
+        if (!(settled && n >= 1 && matesw_insert_wave(opt, b, n, ma, lane))) {
+            if (settled && n >= 1) ++declined;
+            int pos = n;
+            for (int base = 0; base < n; base += 64) {
+                const int kk = base + lane;
+                const uint64_t lower = __ballot(kk < n && ma[kk].score < b.score);
+                if (lower) { pos = base + __ffsll((long long)lower) - 1; break; }
+            }
+            regs_insert_wave(ma, n, pos, b, lane);
+            ++n;
+            settled = n >= 2;
+            ++full;
+            n = sort_dedup_nq_wave(opt, n, ma, keys, lane);
+        }
+    }
+    if (lane == 0) { stat[0] = n; stat[1] = declined; stat[2] = full; }
+}
 __global__ void k_unit_matesw_list(MemOpt opt, AlnReg* ma, int n0, const AlnReg* add, int n_add, int incr, SortKey* keys, int* stat)
 {
     if (threadIdx.x || blockIdx.x) return;
@@ -162,7 +187,8 @@ extern "C" int unit_matesw_list(const MemOpt* opt, void* regs, int n0, const voi
     hipMalloc((void**)&k, (size_t)(n0 + n_add) * sizeof(SortKey) + 16); hipMalloc((void**)&ds, 16);
     hipMemcpy(d, regs, (size_t)n0 * sizeof(AlnReg), hipMemcpyHostToDevice);
     hipMemcpy(da, add, (size_t)n_add * sizeof(AlnReg), hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(k_unit_matesw_list, dim3(1), dim3(64), 0, 0, *opt, d, n0, (const AlnReg*)da, n_add, incr, k, ds);
+    if (incr == 2) hipLaunchKernelGGL(k_unit_matesw_list_wave, dim3(1), dim3(64), 0, 0, *opt, d, n0, (const AlnReg*)da, n_add, k, ds);
+    else hipLaunchKernelGGL(k_unit_matesw_list, dim3(1), dim3(64), 0, 0, *opt, d, n0, (const AlnReg*)da, n_add, incr, k, ds);
     int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -1;
     hipMemcpy(stat3, ds, 12, hipMemcpyDeviceToHost);
     hipMemcpy(regs, d, (size_t)(n0 + n_add) * sizeof(AlnReg), hipMemcpyDeviceToHost);

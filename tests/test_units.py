@@ -256,20 +256,21 @@ def _check_matesw_list(units, n_cases, max_n0, max_add):
         opts = B.set_opt(bytearray(orc.default_options()), max_chain_gap=int(rng.choice([10000, 10000, 100])), mask_level_redun=float(rng.choice([0.95, 0.95, 0.5])))
         ob = ctypes.create_string_buffer(bytes(opts), 168)
         res = []
-        for incr in (0, 1):
+        for incr in (0, 1, 2):                                                 # upstream's sequence, the lane's short cut, the wavefront's
             buf = np.zeros(n0 + n_add, dtype=REG_DTYPE); buf[:n0] = a0
             stat = (ctypes.c_int * 3)()
             assert units.unit_matesw_list(ob, buf.ctypes.data, n0, add.ctypes.data, n_add, incr, stat) == 0
             res.append((stat[0], buf[:stat[0]].tobytes(), stat[1], stat[2]))
         assert res[0][0] == res[1][0] and res[0][1] == res[1][1], (it, n0, n_add, tie_level, res[0][0], res[1][0])
-        assert res[0][3] == n_add
+        assert res[0][0] == res[2][0] and res[0][1] == res[2][1], ("wave", it, n0, n_add, tie_level, res[0][0], res[2][0])
+        assert res[0][3] == n_add and res[1][2:] == res[2][2:]
         fast += n_add - res[1][3]; slow += res[1][3]
     assert fast > 4 * slow, (fast, slow)                                       # the short cut is what normally runs
     return fast, slow
 
 
 def test_units_emu_matesw_list():
-    _check_matesw_list(_load("emu"), 40, 400, 60)
+    _check_matesw_list(_load("emu"), 60, 300, 40)
 
 
 @pytest.mark.gpu
