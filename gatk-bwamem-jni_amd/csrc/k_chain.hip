@@ -388,7 +388,12 @@ __global__ void k_rescore_plan(DevIndex ix, MemOpt opt, TileView tv, SwJob* jobs
             }
             if (pass == 0) {
                 cnt = k;
-                if (cnt > 0) { first = atomicAdd(counter, cnt); if (first + cnt > cap) { atomicOr(tv.err, ERR_JOB_CAP); cnt = 0; } }
+                if (cnt > 0) {
+                    // a reservation of several slots that straddles cap leaves slots below cap unwritten: flag the list as void
+                    // (ERR_RESCUE_CAP: k_pe_rescue_sw and k_rescore_apply return at once, the host re-runs the tile with room)
+                    first = atomicAdd(counter, cnt);
+                    if (first + cnt > cap) { atomicOr(tv.err, ERR_RESCUE_CAP); cnt = 0; }
+                }
                 if (cnt == 0) break;
             }
         }
@@ -401,6 +406,7 @@ __global__ void k_rescore_apply(DevIndex ix, MemOpt opt, TileView tv, const KswR
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= tv.n_reads) return;
     int l_query, min_HSP_score;
+    if (tv.err[0] & ERR_RESCUE_CAP) return;                 // the job list did not fit (k_rescore_plan): this attempt is void
     if (!rescore_read(ix, opt, tv, r, l_query, min_HSP_score)) return;
     const uint8_t* query = tv.seq + tv.seq_off[r];
     int q = first_num[r];

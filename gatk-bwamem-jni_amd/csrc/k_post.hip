@@ -81,6 +81,8 @@ __global__ void __launch_bounds__(64, 6) k_final_prep(DevIndex ix, MemOpt opt, T
             xa = pr >= 0 && !(cnt[pr] > opt.max_XA_hits_alt || (!has_alt[pr] && cnt[pr] > opt.max_XA_hits));
         }
         if ((rec || xa) && region_needs_dp(opt, *p)) {
+            // (one slot per reservation: every slot below job_cap that was handed out gets written, so an overflow leaves no
+            // unwritten slot behind -- unlike the several-slot reservations of k_pe_rescue_plan / k_rescore_plan)
             int job = atomicAdd(tv.job_cnt, 1);
             if (job < tv.job_cap) { DpJob jb; jb.read = r; jb.reg = k; jobs[job] = jb; p->pad_ = job + 1; }
             else atomicOr(tv.err, ERR_JOB_CAP);

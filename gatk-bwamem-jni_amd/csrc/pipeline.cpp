@@ -785,6 +785,7 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
     const uint32_t r0 = spec.r0;
     const int T = (int)(spec.r1 - spec.r0), L = spec.L;
     int attempts = 0, job_cap_hint = 0;
+    bool rescore_full = false;
     size_t zpool_hint = (size_t)64 << 20;
     double zmult = 1;
     { int oc = 0; ix->hints.get(T, job_cap_hint, zmult, oc); out_cap = std::max(out_cap, oc); }
@@ -815,7 +816,11 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
         TIMED(ws, K_SA, launch_sa(ws.stream, ix->d, opt, tv, n_occ));
         TIMED(ws, K_CHAIN, launch_chain(ws.stream, ix->d, opt, tv, ws.chain_store.as<Chain>()));
         if (rescore_needed(opt, tv)) {                     // long reads: seed re-scoring jobs (at most one per seed occurrence)
-            const int rc = (int)std::min<int64_t>(n_occ + 16, 0x7fffffff);
+            if (n_occ + 16 > 0x7fffffff) { fprintf(stderr, "[bwamem_hip] tile with more than 2^31 seed occurrences\n"); return false; }
+            // one job per seed occurrence at most, so n_occ slots always fit; BWAMEM_HIP_RESCORE_CAP0 (tests) makes the first
+            // attempt too small: the plan kernel then voids the list and the tile is run again with the full size
+            static const int cap0 = []{ const char* e = getenv("BWAMEM_HIP_RESCORE_CAP0"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+            const int rc = cap0 && !rescore_full ? cap0 : (int)(n_occ + 16);
             if (!(ws.pe_rescue[0].ensure(pe_rescue_bytes(0, rc)) && ws.pe_rescue[1].ensure(pe_rescue_bytes(1, rc)) && ws.pe_rescue[2].ensure((size_t)T * 8 + 64))) return false;
             TIMED(ws, K_CHAIN, launch_rescore(ws.stream, ix->d, opt, tv, ws.pe_rescue[0].p, ws.pe_rescue[1].p, ws.pe_rescue[2].as<int32_t>() + 16, ws.pe_rescue[2].as<int32_t>(), rc));
         }
@@ -856,6 +861,7 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
         err = errv[0];
         if (err) {
             { std::lock_guard<std::mutex> lk(g_stats.mu); ++g_stats.s.n_retries; }
+            if (err & ERR_RESCUE_CAP) { if (rescore_full) { fprintf(stderr, "[bwamem_hip] internal error: seed re-scoring list beyond the seed count\n"); return false; } rescore_full = true; continue; }
             if (err & ERR_BAD_REG) { fprintf(stderr, "[bwamem_hip] internal error: extension produced an invalid region (tile read %d of call read %lld: n=%d qb=%d qe=%d rb=%d re=%d score=%d)\n", errv[1], (long long)(read_id0 + r0 + errv[1]), errv[2], errv[3], errv[4], errv[5], errv[6], errv[7]); return false; }
             if (err & ERR_LONG_READ) { fprintf(stderr, "[bwamem_hip] reads long enough to need seed re-scoring (mem_flt_chained_seeds) are not supported on the device path yet\n"); return false; }
             if (err & ERR_BTREE) { fprintf(stderr, "[bwamem_hip] internal error: chain B-tree pool exhausted\n"); return false; }
@@ -1124,7 +1130,8 @@ static bool pe_phase1_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
     TIMED(ws, K_SA, launch_sa(ws.stream, ix->d, opt, tv, n_occ));
     TIMED(ws, K_CHAIN, launch_chain(ws.stream, ix->d, opt, tv, ws.chain_store.as<Chain>()));
     if (rescore_needed(opt, tv)) {                     // long reads: seed re-scoring jobs (at most one per seed occurrence)
-        const int rc = (int)std::min<int64_t>(n_occ + 16, 0x7fffffff);
+        if (n_occ + 16 > 0x7fffffff) { fprintf(stderr, "[bwamem_hip] tile with more than 2^31 seed occurrences\n"); return false; }
+        const int rc = (int)(n_occ + 16);                  // one job per seed occurrence at most: the list always fits (see run_tile_se)
         if (!(ws.pe_rescue[0].ensure(pe_rescue_bytes(0, rc)) && ws.pe_rescue[1].ensure(pe_rescue_bytes(1, rc)) && ws.pe_rescue[2].ensure((size_t)T * 8 + 64))) return false;
         TIMED(ws, K_CHAIN, launch_rescore(ws.stream, ix->d, opt, tv, ws.pe_rescue[0].p, ws.pe_rescue[1].p, ws.pe_rescue[2].as<int32_t>() + 16, ws.pe_rescue[2].as<int32_t>(), rc));
     }

@@ -281,3 +281,33 @@ print("rescue-resize-ok")
     env = dict(os.environ, BWAMEM_HIP_PE_RESCUE_CAP0="3")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "rescue-resize-ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_emu_seed_rescoring_list_resized(oracle, small_genome):
+    """the seed re-scoring job list (k_chain.hip: k_rescore_plan) reserves several slots at once, so an overflowing
+    reservation leaves slots below the capacity unwritten: the plan kernel must void the list (ERR_RESCUE_CAP), the alignment
+    and apply kernels must not touch it, and the tile must be run again with room.  BWAMEM_HIP_RESCORE_CAP0 forces a
+    five-slot list on the first attempt.  Own process: the knob is read once."""
+    import subprocess
+    import sys
+    B.build_emu()
+    seqs, img = small_genome
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import bwalib as B
+emu, orc = B.product_lib(emu=True), B.oracle_lib()
+seqs = []
+for blk in open(%r).read().split(">")[1:]:
+    name, _, body = blk.partition("\n")
+    seqs.append((name.strip(), body.replace("\n", "").encode()))
+reads = B.simulate_reads(seqs, 3, length=800, seed=5, sub=0.06, indel=0.02)
+h, ho = emu.open_index(%r), orc.open_index(%r)
+opts = emu.default_options()
+req = B.pack_request(reads)
+assert emu.align_raw(h, opts, req) == orc.align_raw(ho, opts, req)
+print("rescore-resize-ok")
+''' % (os.path.join(B.ROOT, "tests"), img[:-4] if img.endswith(".img") else img, img, img)
+    env = dict(os.environ, BWAMEM_HIP_RESCORE_CAP0="5")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "rescore-resize-ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
