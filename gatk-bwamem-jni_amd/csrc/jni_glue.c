@@ -5,8 +5,10 @@
  * Same symbols, signatures and ownership rules as the reference's glue
  * (src/main/c/org_broadinstitute_hellbender_utils_bwa_BwaMemIndex.c:43-165, init.c:12-29), so the unchanged
  * Java classes load this library through -DLIBBWA_PATH or as the jar resource /libbwa.Linux.so.
- * Needs <jni.h>: compiled only where JAVA_HOME is set (`make jni`); this build image has no JDK, so the file
- * is exercised by the maintainers' Java tests, not by the tests in this repository.
+ * Needs <jni.h>: `make jni` where JAVA_HOME is set.  This build image has no JDK; the tests compile the file against
+ * tests/jni_stub/jni.h (the slice of the JNI it uses, function tables at the specification's indices) and drive
+ * JNI_OnLoad and all nine entry points through a fake JNIEnv (tests/jni_stub/jni_driver.c, tests/test_jni_glue.py):
+ * response bytes against the C ABI's, the BwaMemPairEndStats -> slot 1 mapping, the NULL-buffer and free paths.
  */
 #include <jni.h>
 #include <fcntl.h>
