@@ -60,6 +60,7 @@ struct Stats {
 };
 static Stats g_stats;
 static int g_device = 0;
+static bool g_device_explicit = false;     // bwamem_hip_set_device was called: indexes opened afterwards live on that device only
 
 enum KernelId { K_ENCODE, K_SEED, K_SA, K_CHAIN, K_EXTEND, K_POST, K_FINAL, K_PACK, K_OTHER, K_N };
 
@@ -241,6 +242,11 @@ struct bwaidx_s {
     CapHints hints;
     std::vector<ReqBuf*> req_bufs;      // request stretches of a streamed call (jnibwa_createAlignments)
     hipStream_t up_stream = nullptr;    // their uploads
+    // One handle, several devices (jnibwa_openIndex, BWAMEM_HIP_DEVICES): the handle is the replica on the first device and
+    // owns the others, each a bwaidx_s of its own (index, workspaces, hints) over the same mapped image.
+    std::vector<bwaidx_s*> peers;
+    std::atomic<uint32_t> next_replica{0};   // small calls take the replicas in turn
+    std::mutex split_mu;                     // one call at a time is cut across all replicas (its shards wait for each other while holding their replicas)
 };
 
 struct TileOut { uint8_t* d = nullptr; size_t bytes = 0; bool owned = false; };
@@ -1418,7 +1424,7 @@ template <typename R, typename F> static R guarded(const char* what, R fail, F&&
 
 extern "C" {
 
-int bwamem_hip_set_device(int device) { g_device = device; return hipSetDevice(device) == hipSuccess ? 0 : -1; }
+int bwamem_hip_set_device(int device) { g_device = device; g_device_explicit = true; return hipSetDevice(device) == hipSuccess ? 0 : -1; }
 int bwamem_hip_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 
 void bwamem_hip_stats_enable(int on) { g_stats.enabled = on != 0; }
@@ -1475,6 +1481,35 @@ int jnibwa_createIndexFile(const char* refName, const char* imgName)
     });
 }
 
+// The devices an index opened now goes to.  BWAMEM_HIP_DEVICES: "all" or a comma-separated list of device numbers (a number
+// may be repeated: two replicas on one GPU, which is how the one-GPU test box exercises the multi-device path).  Unset: the
+// device chosen with bwamem_hip_set_device if the process chose one (bench.py's ranks: one per GPU), else every visible
+// device -- a JVM that loads this library on an 8-GPU node then uses all eight (BwaMemIndex.java:16-27: one shared index).
+static std::vector<int> index_devices()
+{
+    std::vector<int> v;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) n = 0;
+    const char* e = getenv("BWAMEM_HIP_DEVICES");
+    if (e && *e && strcmp(e, "all")) {
+        for (const char* p = e; *p; ) {
+            char* end; long d = strtol(p, &end, 10);
+            if (end == p) break;
+            if (d >= 0 && d < n) v.push_back((int)d);
+            p = *end == ',' ? end + 1 : end;
+            if (*end && *end != ',') break;
+        }
+        if (v.empty()) v.push_back(g_device);
+        return v;
+    }
+    if (g_device_explicit && !e) { v.push_back(g_device); return v; }
+    for (int d = 0; d < n; ++d) v.push_back(d);
+    if (v.empty()) v.push_back(g_device);
+    return v;
+}
+
+static void destroy_replica(bwaidx_s* ix) { free_index(ix); delete ix; }
+
 bwaidx_t* jnibwa_openIndex(int fd)
 {
     return guarded("jnibwa_openIndex", (bwaidx_t*)0, [&]() -> bwaidx_t* {
@@ -1483,16 +1518,32 @@ bwaidx_t* jnibwa_openIndex(int fd)
         void* mem = mmap(0, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
         close(fd);
         if (mem == MAP_FAILED) return 0;
-        bwaidx_s* ix = new bwaidx_s();
-        ix->mem = (uint8_t*)mem; ix->l_mem = (size_t)st.st_size; ix->mmapped = true; ix->device = g_device;
-        if (!parse_index_image(ix->mem, ix->l_mem, ix->h) || ix->h.seq_len >= (1ull << 37) || !upload_index(ix)) {   // 37-bit ranks: packed SMEM candidates
+        const std::vector<int> devs = index_devices();
+        std::vector<bwaidx_s*> reps;
+        std::vector<char> ok(devs.size(), 0);
+        for (size_t k = 0; k < devs.size(); ++k) {
+            bwaidx_s* ix = new bwaidx_s();
+            ix->mem = (uint8_t*)mem; ix->l_mem = (size_t)st.st_size; ix->mmapped = k == 0; ix->device = devs[k];
+            reps.push_back(ix);
+        }
+        auto load = [&](size_t k) {
+            try { bwaidx_s* ix = reps[k]; ok[k] = parse_index_image(ix->mem, ix->l_mem, ix->h) && ix->h.seq_len < (1ull << 37) && upload_index(ix); }   // 37-bit ranks: packed SMEM candidates
+            catch (...) { ok[k] = 0; }
+        };
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < reps.size(); ++k) th.emplace_back(load, k);      // every device loads from the one mapped image, side by side
+        load(0);
+        for (std::thread& t : th) t.join();
+        bool all = true;
+        for (char c : ok) all = all && c;
+        if (!all) {
             fprintf(stderr, "[bwamem_hip] cannot open index image (malformed image or no usable HIP device)\n");
-            free_index(ix);
+            for (bwaidx_s* ix : reps) destroy_replica(ix);
             munmap(mem, (size_t)st.st_size);
-            delete ix;
             return 0;
         }
-        return ix;
+        for (size_t k = 1; k < reps.size(); ++k) reps[0]->peers.push_back(reps[k]);
+        return reps[0];
     });
 }
 
@@ -1500,10 +1551,13 @@ int jnibwa_destroyIndex(bwaidx_t* pIdx)
 {
     if (!pIdx) return 0;
     void* mem = pIdx->mem; size_t len = pIdx->l_mem;
-    free_index(pIdx);
-    delete pIdx;
+    for (bwaidx_s* r : pIdx->peers) destroy_replica(r);
+    pIdx->peers.clear();
+    destroy_replica(pIdx);
     return munmap(mem, len);
 }
+
+int bwamem_hip_index_replicas(bwaidx_t* idx) { return idx ? 1 + (int)idx->peers.size() : 0; }
 
 void* jnibwa_getRefContigNames(bwaidx_t* pIdx, size_t* pBufSize)
 {
@@ -1668,6 +1722,97 @@ void bwamem_hip_batch_free(bwamem_batch_t* b)
     delete b;
 }
 
+// One (sub)call on one replica: reads [.., ..+n) of the request starting at payload, numbered from read_id0 within the logical
+// call.  pe_step as in align_batch (1: stop after phase 1 of a paired-end call).  The replica's lock is the caller's business.
+static bwamem_batch_s* new_streamed_batch(bwaidx_s* ix, const char* payload, uint32_t n)
+{
+    bwamem_batch_s* b = new bwamem_batch_s();
+    b->idx = ix; b->n_reads = n; b->h_payload = payload; b->sink.to_host = true;
+    return b;
+}
+
+// A call cut across the replicas of the handle (one contiguous range of reads per device, pairs kept together, each shard
+// numbered from its first read's index in the call: the primary-marking hash needs it).  The request
+// carries no length, so a walker (this thread) finds where each shard starts -- shard k can start as soon as the walk has
+// passed the reads before it -- and every shard then streams its own range as a call of its own.  A paired-end call with
+// inferred insert-size statistics stops every shard after phase 1, reduces all shards' candidates on the host (upstream's
+// mem_pestat is a reduction over the whole call) and finishes every shard with the same statistics.
+static void* create_alignments_split(bwaidx_s* ix0, const MemOpt& o, const MemPestat* pes0, const char* payload, uint32_t n, size_t* out_bytes)
+{
+    std::vector<bwaidx_s*> reps; reps.push_back(ix0);
+    for (bwaidx_s* r : ix0->peers) reps.push_back(r);
+    const bool pe = (o.flag & MEM_F_PE) != 0, two_step = pe && !pes0;
+    int D = (int)reps.size();
+    if ((uint64_t)D > (uint64_t)n / (pe ? 2 : 1)) D = std::max<int>(1, (int)(n / (pe ? 2 : 1)));
+    struct Shard { const char* p = nullptr; uint32_t n = 0; int64_t id0 = 0; bool ready = false, p1_done = false, ok = false; bwamem_batch_s* b = nullptr; void* res = nullptr; size_t bytes = 0; };
+    std::vector<Shard> sh((size_t)D);
+    uint32_t share = n / (uint32_t)D;
+    if (pe) share &= ~1u;
+    for (int k = 0; k < D; ++k) { sh[k].n = k + 1 < D ? share : n - share * (uint32_t)(D - 1); sh[k].id0 = (int64_t)share * k; }
+    std::mutex mu; std::condition_variable cv;
+    bool failed = false, stats_ready = false;
+    MemPestat pes[4];
+    std::lock_guard<std::mutex> split_lk(ix0->split_mu);
+    auto run = [&](int k) {
+        bool ok = false;
+        try {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return sh[k].ready || failed; }); if (failed) { sh[k].p1_done = true; cv.notify_all(); return; } }
+            bwaidx_s* ix = reps[k];
+            std::lock_guard<std::mutex> ilk(ix->mu);
+            sh[k].b = new_streamed_batch(ix, sh[k].p, sh[k].n);
+            ok = align_batch(ix, o, pes0, sh[k].b, sh[k].id0, two_step ? 1 : 0);
+            if (two_step) {
+                { std::lock_guard<std::mutex> lk(mu); sh[k].p1_done = true; if (!ok) failed = true; }
+                cv.notify_all();
+                { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stats_ready || failed; }); ok = ok && !failed; }
+                if (ok) ok = hipSetDevice(ix->device) == hipSuccess && pe_finish(ix, o, pes, sh[k].b);
+                else pe_call_free(sh[k].b);
+            }
+            if (ok) { sh[k].bytes = sh[k].b->result_bytes; sh[k].res = sh[k].b->sink.take(sh[k].bytes); ok = sh[k].res != nullptr; }
+        } catch (const std::exception& ex) { fprintf(stderr, "[bwamem_hip] createAlignments shard %d: %s\n", k, ex.what()); ok = false; }
+          catch (...) { ok = false; }
+        { std::lock_guard<std::mutex> lk(mu); sh[k].ok = ok; sh[k].p1_done = true; if (!ok) failed = true; }
+        cv.notify_all();
+    };
+    std::vector<std::thread> th;
+    for (int k = 0; k < D; ++k) th.emplace_back(run, k);
+    {   // the walk: shard k starts where the reads before it end
+        const char* p = payload;
+        for (int k = 0; k < D; ++k) {
+            { std::lock_guard<std::mutex> lk(mu); sh[k].p = p; sh[k].ready = true; }
+            cv.notify_all();
+            if (k + 1 < D) { uint64_t got = 0; p = scan_reads(p, sh[k].n, (size_t)-1, &got); }
+        }
+    }
+    if (two_step) {
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { for (const Shard& s : sh) if (!s.p1_done) return false; return true; }); }
+        bool ok; { std::lock_guard<std::mutex> lk(mu); ok = !failed; }
+        if (ok) {
+            std::vector<int8_t> dir, d1; std::vector<int64_t> is, i1;
+            for (const Shard& s : sh) { pe_candidates(s.b, d1, i1); dir.insert(dir.end(), d1.begin(), d1.end()); is.insert(is.end(), i1.begin(), i1.end()); }
+            host_pestat(o, dir, is, pes);
+        }
+        { std::lock_guard<std::mutex> lk(mu); stats_ready = true; }
+        cv.notify_all();
+    }
+    for (std::thread& t : th) t.join();
+    void* res = nullptr;
+    size_t total = 0;
+    if (!failed) {
+        for (const Shard& s : sh) total += s.bytes;
+        res = malloc(total ? total : 1);
+        if (res) {
+            std::vector<std::thread> cp;
+            size_t off = 0;
+            for (const Shard& s : sh) { uint8_t* dst = (uint8_t*)res + off; cp.emplace_back([dst, &s] { if (s.bytes) memcpy(dst, s.res, s.bytes); }); off += s.bytes; }
+            for (std::thread& t : cp) t.join();
+        }
+    }
+    for (Shard& s : sh) { if (s.res) free(s.res); if (s.b) bwamem_hip_batch_free(s.b); }
+    if (res && out_bytes) *out_bytes = total;
+    return res;
+}
+
 void* jnibwa_createAlignments(bwaidx_t* pIdx, mem_opt_t* pOpts, mem_pestat_t* peStats, char* pSeq, size_t* pBufSize)
 {
     if (pBufSize) *pBufSize = 0;
@@ -1676,20 +1821,41 @@ void* jnibwa_createAlignments(bwaidx_t* pIdx, mem_opt_t* pOpts, mem_pestat_t* pe
     // copies the records out.  Here the three overlap: a producer thread walks the buffer and streams it to the device
     // stretch by stretch (read offsets are found there), tiles are aligned as soon as their stretch is resident, and every
     // finished tile's records go straight into the malloc'ed block that is returned.
+    // With several replicas behind the handle (jnibwa_openIndex): a large call is cut across all of them; a small one goes to
+    // the next replica in turn (the first free one from there), so that concurrent callers of one BwaMemIndex
+    // (BwaMemIndex.java:16-27) spread over the devices instead of queueing on one.
     void* res = 0;
     RoctxRange rr("jnibwa_createAlignments");
     try {
         uint32_t n; memcpy(&n, pSeq, 4);
-        bwamem_batch_s* b = new bwamem_batch_s();
-        b->idx = pIdx; b->n_reads = n; b->h_payload = pSeq + 4; b->sink.to_host = true;
-        {
-            std::lock_guard<std::mutex> lk(pIdx->mu);
-            MemOpt o; memcpy(&o, pOpts, sizeof o);
-            if (align_batch(pIdx, o, (const MemPestat*)peStats, b, 0)) {
-                res = b->sink.take(b->result_bytes);
-                if (res && pBufSize) *pBufSize = b->result_bytes;
+        MemOpt o; memcpy(&o, pOpts, sizeof o);
+        const int D = 1 + (int)pIdx->peers.size();
+        if (D > 1) {
+            static const long split_min = []{ const char* e = getenv("BWAMEM_HIP_SPLIT_MIN"); return e && atol(e) > 0 ? atol(e) : 131072L; }();   // reads per replica below which cutting a call does not pay
+            if ((long)n >= split_min * D && n >= 2u * (unsigned)D) {
+                size_t bytes = 0;
+                res = create_alignments_split(pIdx, o, (const MemPestat*)peStats, pSeq + 4, n, &bytes);
+                if (res && pBufSize) *pBufSize = bytes;
+                return res;
             }
         }
+        bwaidx_s* ix = pIdx;
+        std::unique_lock<std::mutex> lk;
+        if (D > 1) {
+            const uint32_t first = pIdx->next_replica.fetch_add(1);
+            for (int i = 0; i < D && !lk.owns_lock(); ++i) {
+                bwaidx_s* r = (first + i) % D == 0 ? pIdx : pIdx->peers[(first + i) % D - 1];
+                std::unique_lock<std::mutex> t(r->mu, std::try_to_lock);
+                if (t.owns_lock()) { lk = std::move(t); ix = r; }
+            }
+            if (!lk.owns_lock()) { ix = first % D == 0 ? pIdx : pIdx->peers[first % D - 1]; lk = std::unique_lock<std::mutex>(ix->mu); }
+        } else lk = std::unique_lock<std::mutex>(ix->mu);
+        bwamem_batch_s* b = new_streamed_batch(ix, pSeq + 4, n);
+        if (align_batch(ix, o, (const MemPestat*)peStats, b, 0)) {
+            res = b->sink.take(b->result_bytes);
+            if (res && pBufSize) *pBufSize = b->result_bytes;
+        }
+        lk.unlock();
         bwamem_hip_batch_free(b);
     } catch (const std::exception& ex) { fprintf(stderr, "[bwamem_hip] createAlignments: %s\n", ex.what()); res = 0; }
       catch (...) { res = 0; }

@@ -56,8 +56,13 @@ const char* jnibwa_getVersion(void);
 /* ------------------------------------------------------------------------------------------------
  * Additive device-level entry points (bench, multi-GPU drivers).  Not part of the reference ABI. */
 
-int bwamem_hip_set_device(int device);        /* device used by subsequently opened indexes */
+int bwamem_hip_set_device(int device);        /* indexes opened afterwards live on this one device (one process per GPU: bench.py's ranks) */
 int bwamem_hip_device_count(void);
+/* jnibwa_openIndex puts a replica of the index on every device named by BWAMEM_HIP_DEVICES ("all", or e.g. "0,1,2,3"; unset: the
+ * device of bwamem_hip_set_device if that was called, else all visible devices); jnibwa_createAlignments (jnibwa.c:197-235: one
+ * native call per batch) then cuts a large call across the replicas and sends small concurrent calls to them in turn.
+ * -> the number of replicas behind the handle. */
+int bwamem_hip_index_replicas(bwaidx_t* idx);
 
 /* Tooling (bench.py --image): the contig lengths of an open index (returns the number of contigs; lens may be NULL), and
  * n bases of its packed reference from position start, one code 0..3 per byte, into DEVICE memory d_dst.  0 = ok. */
