@@ -2,6 +2,7 @@
 committed golden vectors.  Bit-exact is the bar: all arithmetic on the path is integer / byte /
 index work (the few float/double decisions must round identically)."""
 import json
+import struct
 import os
 import sys
 
@@ -531,3 +532,59 @@ def test_paired_end_on_repeat_rich_genome(tmp_path):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["parity_sample"]["reads"] == 60000 and out["parity_sample"]["frac_identical_records"] == 1.0, out["parity_sample"]
     assert out["host_to_host"]["identical_to_resident_response"] is True
+
+
+HUMANLIKE_CODE = r"""
+import os, struct, sys
+import torch                                     # (first: the process then has one HIP runtime, torch's, as in bench.py)
+sys.path[:0] = [%(tests)r, %(root)r, %(pkg)r]
+import bwalib as B
+import bench
+import index_build_gpu as G
+hip_lib, oracle = B.product_lib(), B.oracle_lib()
+dev = torch.device("cuda", 0)
+codes, contigs = bench.synth_genome_humanlike(torch, dev, 16_000_000, 3, 0x5EED)
+img = os.path.join(%(workdir)r, "hl16.img")
+G.write_image(img, G.build_pieces(codes), contigs)
+n_se, n_pe = 100_000, 60_000
+se = bench.synth_reads(torch, dev, codes, contigs, n_se, 150, 42)
+pe = bench.synth_pairs(torch, dev, codes, contigs, n_pe // 2, 150, 43)
+del codes
+torch.cuda.empty_cache()
+h, ho = hip_lib.open_index(img), oracle.open_index(img)
+assert h and ho
+cores = min(16, len(os.sched_getaffinity(0)))
+for payload, n, flag, stats in ((se, n_se, 0, [None]), (pe, n_pe, B.MEM_F_PE, [None, B.pack_pestat(200, 600, 400.0, 50.0)])):
+    req = struct.pack("<i", n) + payload.cpu().numpy().tobytes()
+    for pes in stats:
+        opts = B.set_opt(hip_lib.default_options(), flag=flag)
+        want = oracle.align_raw(ho, B.set_opt(bytearray(opts), n_threads=cores), req, pes)
+        got = hip_lib.align_raw(h, opts, req, pes)
+        assert got is not None
+        if got != want:
+            a, b = B.split_response(got, n), B.split_response(want, n)
+            bad = [i for i in range(n) if a[i] != b[i]]
+            raise AssertionError("%%d of %%d reads differ (first: %%s), flag %%d, statistics %%s" %% (len(bad), n, bad[:10], flag, "supplied" if pes else "inferred"))
+        recs = B.decode_response(got, n)
+        # the workload is what it claims to be: mapped reads with MAPQ 0 (several equally good places) occur by the hundred
+        assert sum(1 for r in recs if r and r[0].get("mapq", 60) == 0 and not r[0]["flag"] & 4) > 50
+hip_lib.destroy_index(h); oracle.destroy_index(ho)
+print("humanlike-parity-ok")
+"""
+
+
+@pytest.mark.gpu
+def test_parity_humanlike_16mbp_single_and_paired_end(hip_lib, oracle, workdir):
+    """A 16 Mbp genome with human-like repeat content (SINE-/LINE-like families, satellite arrays, microsatellites, segmental
+    duplications: bench.py's generator, scaled down), index built on the device, 100 000 single-end reads and 60 000 paired-end
+    reads (statistics inferred, then supplied) straight through the C ABI against the oracle, every record compared.  The small
+    genomes of the other tests have nothing like a satellite array: reads with hundreds of regions, pairs with dozens of
+    rescue anchors and the wavefront forms of chain filtering and mate rescue are only reached here.  Own process: the genome
+    and the index are made with torch on the GPU, and torch has to initialise HIP before this library does."""
+    import subprocess
+    code = HUMANLIKE_CODE % dict(tests=os.path.join(B.ROOT, "tests"), root=B.ROOT, pkg=B.PKG, workdir=workdir)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "humanlike-parity-ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
