@@ -11,6 +11,7 @@
 // observable through the window-growth rule.  Integer scoring throughout: no MFMA.
 #include "dev_common.h"
 #include "wave_ops.h"
+#include "pk16.h"
 #include "kernels.h"
 
 struct ExtRes { int score, qle, tle, gtle, gscore, max_off; };
@@ -340,6 +341,159 @@ static __device__ ExtRes extend_wave_reg(const DevIndex& ix, const MemOpt& opt, 
     return r;
 }
 
+// The register form for queries of 64 .. 126 bases -- two thirds of the DP rows of 150 bp reads -- with its two 64-column
+// chunks packed into the halves of one register (pk16.h): lane l holds column l in the low half and column 64 + l in the high
+// half of every row register, and one stream of packed 16-bit instructions computes both.  What cannot be packed stays
+// 32-bit: the row maximum with its column (one scan over the larger of the two chunks' keys) and the cross-lane moves (DPP
+// applies to 32-bit moves; the move carries both halves).  Two details differ from the 32-bit form, neither observable:
+// the prefix maximum behind F uses 0 instead of -infinity as its identity (U >= 0 always; a phantom 0 only adds F
+// candidates <= 0, and F <= 0 never decides anything because E >= 0 is in the same maximum), and dead columns take part in
+// it with tt = 0 (same argument).  Usable when every score fits 16 bits: extend_pk2_ok().
+static __device__ inline bool extend_pk2_ok(const MemOpt& opt, int qlen, int h0, int mx)
+{
+    return qlen + 1 > WAVE && qlen + 1 <= 2 * WAVE && opt.e_ins >= 0 && opt.e_del >= 0 && opt.o_ins >= 0 && opt.o_del >= 0 && mx > 0
+        && (long long)(h0 > 0 ? h0 : 0) + (long long)qlen * mx + 130ll * opt.e_ins < 30000 && opt.o_ins + opt.e_ins < 30000 && opt.o_del + opt.e_del < 30000;
+}
+#define PK_DPP_ZERO(v, ctrl, rowmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rowmask), 0xf, (rowmask) == 0xf))
+static __device__ ExtRes extend_wave_pk2(const DevIndex& ix, const MemOpt& opt, const uint8_t* query, int lane,
+                                         int qlen, int q0, int qstep, int tlen, int64_t t0, int tstep,
+                                         int w, int end_bonus, int zdrop, int h0, unsigned long long& n_cells)
+{
+    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    int i, beg, end, max, max_i, max_j, max_ins, max_del, max_ie, gscore, max_off;
+    const ScoreTab ST = score_tab(opt);
+    if (h0 < 0) h0 = 0;
+    uint32_t ehh, ehe = 0, scp_lo, scp_hi;
+    {   // first row: decay from h0 by insertion costs
+        int v[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int j = t * WAVE + lane;
+            v[t] = 0;
+            if (j == 0) v[t] = h0;
+            else if (j <= qlen && h0 > oe_ins) { const int vj = h0 - oe_ins - (j - 1) * e_ins; if (j == 1 || vj > 0) v[t] = vj; }
+        }
+        ehh = pk_pair(v[0], v[1]);
+        int sn;
+        score_lane(ST, lane < qlen ? query[q0 + qstep * lane] : 4, scp_lo, sn);
+        score_lane(ST, lane + WAVE < qlen ? query[q0 + qstep * (lane + WAVE)] : 4, scp_hi, sn);
+    }
+    const uint32_t je = pk_pair(lane * e_ins, (lane + WAVE) * e_ins);
+    const uint32_t jm1e = pk_pair(lane == 0 ? 0 : (lane - 1) * e_ins, (lane + WAVE - 1) * e_ins);   // (column 0 has no F: with 0 here it gets F = 0)
+    const uint32_t OEI = pk_both(oe_ins), OED = pk_both(oe_del), ED = pk_both(e_del), ONE = pk_both(1);
+    const int jhi = lane + WAVE;
+    const int mx = score_max(opt);
+    {
+        max_ins = div_plus(qlen * mx + end_bonus - o_ins, e_ins, 1);
+        max_ins = max_ins > 1 ? max_ins : 1;
+        w = w < max_ins ? w : max_ins;
+        max_del = div_plus(qlen * mx + end_bonus - o_del, e_del, 1);
+        max_del = max_del > 1 ? max_del : 1;
+        w = w < max_del ? w : max_del;
+    }
+    max = h0; max_i = max_j = -1; max_ie = -1; gscore = -1; max_off = 0;
+    beg = 0; end = qlen;
+    int tch = 4;
+    for (i = 0; i < tlen; ++i) {
+        if ((i & 63) == 0) { int ii = i + lane; tch = ii < tlen ? ref_base2(ix, t0 + (int64_t)tstep * ii) : 4; }
+        const int tb = wave_readlane(tch, i & 63);
+        int m, mj, h1, h1i;
+        if (beg < i - w) beg = i - w;
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        if (beg == 0) { h1i = h0 - (o_del + e_del * (i + 1)); if (h1i < 0) h1i = 0; }
+        else h1i = 0;
+        h1 = h1i;
+        const int pos1 = end > beg ? beg : end;            // the column whose eh.h becomes the first-column value
+        const bool a_lo = lane >= beg && lane < end, a_hi = jhi >= beg && jhi < end;
+        const uint32_t am = (a_lo ? 0xffffu : 0u) | (a_hi ? 0xffff0000u : 0u);
+        const uint32_t sc = pk_pair((int)(int8_t)(scp_lo >> (tb << 3)), (int)(int8_t)(scp_hi >> (tb << 3)));
+        const uint32_t Mp = ehh, e = ehe;
+        const uint32_t M = pk_mul(pk_minu(Mp, ONE), pk_add(Mp, sc)) & am;      // M = live && Mp ? Mp + sc : 0 (Mp >= 0)
+        const uint32_t tt = pk_max(pk_sub(M, OEI), 0u);
+        uint32_t P = pk_add(tt, je);                                           // U, then its inclusive prefix maximum per half
+        P = pk_max(P, PK_DPP_ZERO(P, DPP_ROW_SHR(1), 0xf));
+        P = pk_max(P, PK_DPP_ZERO(P, DPP_ROW_SHR(2), 0xf));
+        P = pk_max(P, PK_DPP_ZERO(P, DPP_ROW_SHR(4), 0xf));
+        P = pk_max(P, PK_DPP_ZERO(P, DPP_ROW_SHR(8), 0xf));
+        P = pk_max(P, PK_DPP_ZERO(P, DPP_ROW_BCAST15, 0xa));
+        P = pk_max(P, PK_DPP_ZERO(P, DPP_ROW_BCAST31, 0xc));
+        uint32_t Pex = PK_DPP_ZERO(P, DPP_WAVE_SHR1, 0xf);
+        Pex = pk_max(Pex, (uint32_t)wave_readlane((int)P, 63) << 16);          // the second chunk continues the first one's scan
+        const uint32_t f = pk_sub(Pex, jm1e);
+        uint32_t h = pk_max(pk_max(M, e), f);
+        h = (h & am) | ~am;                                                    // -1 outside the live columns
+        // row maximum with the last column that attains it: one scan over (h, column) keys
+        const int klo = (int)((uint32_t)(int)(int16_t)(h & 0xffffu) << 8) | lane, khi = (int)((uint32_t)((int)h >> 16) << 8) | jhi;
+        const int best = wave_readlane(dpp_prefix_max(klo > khi ? klo : khi, -1), 63);
+        const uint32_t t2 = pk_max(pk_sub(M, OED), 0u);
+        const uint32_t en = pk_max(pk_sub(e, ED), t2);
+        if (end > beg) { const int v = wave_readlane((int)h, (end - 1) & 63); h1 = ((end - 1) >> 6) ? v >> 16 : (int)(int16_t)(v & 0xffff); }
+        // in-place row update: eh[pos1].h = h1i, eh[j+1].h = H(i,j) for the live columns, eh[j].e = E(i+1,j), eh[end].e = 0
+        const uint32_t fill = (uint32_t)wave_readlane((int)h, 63) << 16 | 0xffffu;       // lane 0: nothing left of column 0, column 63 left of column 64
+        const uint32_t hsh = (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)h, DPP_WAVE_SHR1, 0xf, 0xf, false);
+        const uint32_t dead = pk_sra15(hsh);                                   // halves whose left neighbour was not live keep their value
+        ehh = (ehh & dead) | (hsh & ~dead);
+        {
+            const uint32_t half = (pos1 >> 6) ? 0xffff0000u : 0xffffu;
+            ehh = lane == (pos1 & 63) ? (ehh & ~half) | (pk_both(h1i) & half) : ehh;
+        }
+        ehe = (en & am) | (ehe & ~am);
+        {
+            const uint32_t half = (end >> 6) ? 0xffff0000u : 0xffffu;
+            ehe = lane == (end & 63) ? ehe & ~half : ehe;
+        }
+        m = best < 0 ? 0 : best >> 8;
+        mj = best < 0 ? -1 : best & 255;
+        if (end > beg) n_cells += (unsigned long long)(end - beg);
+        {
+            const int jafter = end > beg ? end : beg;
+            if (jafter == qlen) {
+                max_ie = gscore > h1 ? max_ie : i;
+                gscore = gscore > h1 ? gscore : h1;
+            }
+        }
+        if (m == 0) break;
+        if (m > max) {
+            max = m; max_i = i; max_j = mj;
+            int d = mj - i; d = d < 0 ? -d : d;
+            max_off = max_off > d ? max_off : d;
+        } else if (zdrop > 0) {
+            if (i - max_i > mj - max_j) {
+                if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
+            } else {
+                if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
+            }
+        }
+        {   // shrink the window to the non-zero span of the row just written
+            const uint32_t nz = ehh | ehe;
+            const unsigned long long nzl = wave_ballot((nz & 0xffffu) != 0), nzh = wave_ballot((nz >> 16) != 0);
+            const unsigned long long fl = nzl & wave_ballot(a_lo), fh = nzh & wave_ballot(a_hi);
+            beg = fl ? __ffsll((long long)fl) - 1 : fh ? WAVE + __ffsll((long long)fh) - 1 : end;
+            const unsigned long long gl = nzl & wave_ballot(lane >= beg && lane <= end), gh = nzh & wave_ballot(jhi >= beg && jhi <= end);
+            const int jl = gh ? WAVE + 63 - __clzll((long long)gh) : gl ? 63 - __clzll((long long)gl) : beg - 1;
+            end = jl + 2 < qlen ? jl + 2 : qlen;
+        }
+        if (gscore > 0 && m + mx * (qlen - 1 - mj) <= max) {   // see ext_bound(): the remaining rows cannot change the result
+            int B = 0;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int j = t * WAVE + lane;
+                const int hh = t ? (int)ehh >> 16 : (int)(int16_t)(ehh & 0xffffu), ee = t ? (int)ehe >> 16 : (int)(int16_t)(ehe & 0xffffu);
+                const int term = j >= beg && j < qlen ? ext_bound_term(hh, ee, mx, qlen - 1 - j) : 0;
+                const int bc = wave_readlane(dpp_prefix_max(term, 0), 63);
+                B = B > bc ? B : bc;
+            }
+            if (beg == 0) { const int hb = h0 - (o_del + e_del * (i + 2)); if (hb > 0 && hb + mx * qlen > B) B = hb + mx * qlen; }
+            if (B <= max && B < gscore) break;
+        }
+    }
+    ExtRes r;
+    r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+    return r;
+}
+
 // The diagonal certificate: many extensions of well-placed reads run along the seed's diagonal with at most one mismatch,
 // and then the banded DP is decided before it starts.  Let s_j = mat[t_j][q_j] be the scores on the diagonal, a = max(mat),
 // D = sum_j (a - s_j) over the whole query (the "deficit") and g = min(o_del + e_del, o_ins + e_ins).  A path from the origin
@@ -400,10 +554,11 @@ static __device__ bool extend_diag(const DevIndex& ix, const MemOpt& opt, const 
 // picks the register-resident form when the query fits
 static __device__ ExtRes extend_any(const DevIndex& ix, const MemOpt& opt, const ExtLds& L, int lane,
                                     int qlen, int q0, int qstep, int tlen, int64_t t0, int tstep,
-                                    int w, int end_bonus, int zdrop, int h0, unsigned long long& n_cells, bool try_diag)
+                                    int w, int end_bonus, int zdrop, int h0, unsigned long long& n_cells, bool try_diag, bool pk2 = true)
 {
     { ExtRes r; if (try_diag && extend_diag(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, zdrop, h0, r)) return r; }
     if (qlen + 1 <= WAVE) return extend_wave_reg<1>(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
+    if (pk2 && extend_pk2_ok(opt, qlen, h0, score_max(opt))) return extend_wave_pk2(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
     if (qlen + 1 <= 2 * WAVE) return extend_wave_reg<2>(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
     if (qlen + 1 <= 3 * WAVE) return extend_wave_reg<3>(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
     return extend_wave(ix, opt, L, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);

@@ -1,0 +1,33 @@
+// pk16.h -- two 16-bit integers per 32-bit register (the v_pk_*_i16 / _u16 instructions of gfx9+).
+//
+// Used by the packed form of the extension DP (k_extend.hip: extend_wave_pk2): two 64-column chunks of a DP row share one
+// instruction stream, the low half of every register holding a column of the first chunk and the high half the same lane's
+// column of the second.  The device compiler gets clang's two-element vector types, which it selects to the packed
+// instructions; the g++ build of the test emulation (tests/emu) computes the same per half.
+#pragma once
+#include <stdint.h>
+#include "dev_common.h"
+
+#if defined(__clang__)
+typedef short pk_s16_t __attribute__((ext_vector_type(2)));
+typedef unsigned short pk_u16_t __attribute__((ext_vector_type(2)));
+DEV uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (pk_s16_t)(__builtin_bit_cast(pk_s16_t, a) + __builtin_bit_cast(pk_s16_t, b))); }
+DEV uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (pk_s16_t)(__builtin_bit_cast(pk_s16_t, a) - __builtin_bit_cast(pk_s16_t, b))); }
+DEV uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pk_s16_t, a), __builtin_bit_cast(pk_s16_t, b))); }
+DEV uint32_t pk_minu(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(pk_u16_t, a), __builtin_bit_cast(pk_u16_t, b))); }
+DEV uint32_t pk_mul(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (pk_u16_t)(__builtin_bit_cast(pk_u16_t, a) * __builtin_bit_cast(pk_u16_t, b))); }
+DEV uint32_t pk_sra15(uint32_t a) { return __builtin_bit_cast(uint32_t, (pk_s16_t)(__builtin_bit_cast(pk_s16_t, a) >> (pk_s16_t)15)); }   // 0xffff where the half is negative
+#else
+DEV uint32_t pk_join(int lo, int hi) { return (uint32_t)(uint16_t)lo | (uint32_t)(uint16_t)hi << 16; }
+DEV int pk_lo_(uint32_t a) { return (int16_t)(a & 0xffffu); }
+DEV int pk_hi_(uint32_t a) { return (int16_t)(a >> 16); }
+DEV uint32_t pk_add(uint32_t a, uint32_t b) { return pk_join(pk_lo_(a) + pk_lo_(b), pk_hi_(a) + pk_hi_(b)); }
+DEV uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_join(pk_lo_(a) - pk_lo_(b), pk_hi_(a) - pk_hi_(b)); }
+DEV uint32_t pk_max(uint32_t a, uint32_t b) { return pk_join(pk_lo_(a) > pk_lo_(b) ? pk_lo_(a) : pk_lo_(b), pk_hi_(a) > pk_hi_(b) ? pk_hi_(a) : pk_hi_(b)); }
+DEV uint32_t pk_minu(uint32_t a, uint32_t b) { const uint32_t al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16; return (al < bl ? al : bl) | (ah < bh ? ah : bh) << 16; }
+DEV uint32_t pk_mul(uint32_t a, uint32_t b) { return ((a & 0xffffu) * (b & 0xffffu) & 0xffffu) | ((a >> 16) * (b >> 16) & 0xffffu) << 16; }
+DEV uint32_t pk_sra15(uint32_t a) { return (a & 0x8000u ? 0xffffu : 0u) | (a & 0x80000000u ? 0xffff0000u : 0u); }
+#endif
+// both halves = the 16 low bits of x / the two halves from two ints
+DEV uint32_t pk_both(int x) { return (uint32_t)(uint16_t)x * 0x10001u; }
+DEV uint32_t pk_pair(int lo, int hi) { return (uint32_t)(uint16_t)lo | (uint32_t)(uint16_t)hi << 16; }

@@ -91,9 +91,46 @@ def _check_extend(units, oracle, n_cases, max_q):
                   ctypes.byref(want, 0), ctypes.byref(want, 4), ctypes.byref(want, 8), ctypes.byref(want, 12), ctypes.byref(want, 16))
         got = (ctypes.c_int * 6)()
         ob = ctypes.create_string_buffer(bytes(opts), 168)
-        for force_lds in (0, 1, 2):       # the register-resident form (when the query fits), the general LDS form, and the production entry (diagonal certificate first)
+        for force_lds in (0, 1, 2, 3):    # the 32-bit register forms (when the query fits), the general LDS form, the production entry (diagonal certificate first,
+                                          # packed 16-bit form for 64..126-base queries), and the same without the certificate
             assert units.unit_extend(q.tobytes(), qlen, t.tobytes(), tlen, ob, w, end_bonus, zdrop, h0, got, force_lds) == 0
             assert list(got) == [ws, want[0], want[1], want[2], want[3], want[4]], (it, force_lds, qlen, tlen, kw, w, zdrop, h0)
+
+
+def _check_extend_16bit_boundary(units, oracle):
+    """the packed form of the two-chunk extension keeps its scores in 16-bit halves and must hand a query over to the 32-bit
+    form when they could not fit (k_extend.hip: extend_pk2_ok, h0 + qlen * max score + 130 e_ins < 30000): match scores of 127
+    and initial scores on either side of that line, with mismatches and a gap so that the rows are real DP"""
+    oext = oracle.dll.o_ksw_extend2
+    oext.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p] * 5
+    rng = np.random.default_rng(5)
+    base_opts = oracle.default_options()
+    for qlen in (126, 100, 65):
+        for e_ins in (1, 3):
+            edge = 30000 - qlen * 127 - 130 * e_ins
+            for h0 in (edge - 1, edge, edge + 7, 200):
+                kw = dict(a=127, b=100, o_del=60, e_del=10, o_ins=60, e_ins=e_ins)
+                tlen = qlen + 40
+                t = rng.integers(0, 4, size=tlen, dtype=np.uint8)
+                q = t[:qlen].copy()
+                for pos in rng.integers(5, qlen - 5, size=3):
+                    q[pos] = (q[pos] + 1) % 4
+                q = np.concatenate([q[:40], q[42:], rng.integers(0, 4, size=2, dtype=np.uint8)])      # a two-base deletion
+                opts = B.set_opt(bytearray(base_opts), **kw)
+                mat = []
+                for i in range(4):
+                    mat += [kw["a"] if i == j else -kw["b"] for j in range(4)] + [-1]
+                mat += [-1] * 5
+                B.set_opt(opts, mat=mat)
+                want = (ctypes.c_int * 5)()
+                ws = oext(qlen, q.tobytes(), tlen, t.tobytes(), 5, bytes(opts[140:165]), kw["o_del"], kw["e_del"], kw["o_ins"], kw["e_ins"], 100, 5, 0, h0,
+                          ctypes.byref(want, 0), ctypes.byref(want, 4), ctypes.byref(want, 8), ctypes.byref(want, 12), ctypes.byref(want, 16))
+                ob = ctypes.create_string_buffer(bytes(opts), 168)
+                got = (ctypes.c_int * 6)()
+                for mode in (0, 3):
+                    assert units.unit_extend(q.tobytes(), qlen, t.tobytes(), tlen, ob, 100, 5, 0, h0, got, mode) == 0
+                    assert list(got) == [ws, want[0], want[1], want[2], want[3], want[4]], (qlen, e_ins, h0, mode, list(got), ws, list(want))
+                assert ws > 5000                                       # (the scores really are beyond what a byte or a careless 16-bit sum holds)
 
 
 def test_units_emu_sort(oracle):
@@ -102,6 +139,7 @@ def test_units_emu_sort(oracle):
 
 def test_units_emu_extend(oracle):
     _check_extend(_load("emu"), oracle, 60, 230)
+    _check_extend_16bit_boundary(_load("emu"), oracle)
 
 
 @pytest.mark.gpu
@@ -112,6 +150,7 @@ def test_units_gpu_sort(oracle):
 @pytest.mark.gpu
 def test_units_gpu_extend(oracle):
     _check_extend(_load("hip"), oracle, 1500, 300)
+    _check_extend_16bit_boundary(_load("hip"), oracle)
 
 
 def _flt_reference(qb, qe, w, alt, mask_level, drop_ratio, max_chain_gap, min_seed_len):
