@@ -381,7 +381,8 @@ static __device__ ExtRes extend_wave_pk2(const DevIndex& ix, const MemOpt& opt, 
     }
     const uint32_t je = pk_pair(lane * e_ins, (lane + WAVE) * e_ins);
     const uint32_t jm1e = pk_pair(lane == 0 ? 0 : (lane - 1) * e_ins, (lane + WAVE - 1) * e_ins);   // (column 0 has no F: with 0 here it gets F = 0)
-    const uint32_t OEI = pk_both(oe_ins), OED = pk_both(oe_del), ED = pk_both(e_del), ONE = pk_both(1);
+    const uint32_t OEIB = pk_both(oe_ins + 128), OEDB = pk_both(oe_del + 128), ED = pk_both(e_del), ONE = pk_both(1), BIAS = pk_both(128);
+    scp_lo ^= 0x80808080u; scp_hi ^= 0x80808080u;            // score + 128 as an unsigned byte
     const int jhi = lane + WAVE;
     const int mx = score_max(opt);
     {
@@ -408,10 +409,13 @@ static __device__ ExtRes extend_wave_pk2(const DevIndex& ix, const MemOpt& opt, 
         const int pos1 = end > beg ? beg : end;            // the column whose eh.h becomes the first-column value
         const bool a_lo = lane >= beg && lane < end, a_hi = jhi >= beg && jhi < end;
         const uint32_t am = (a_lo ? 0xffffu : 0u) | (a_hi ? 0xffff0000u : 0u);
-        const uint32_t sc = pk_pair((int)(int8_t)(scp_lo >> (tb << 3)), (int)(int8_t)(scp_hi >> (tb << 3)));
+        // M = live && Mp ? Mp + score : 0.  The scores sit in the lane as bytes biased by 128 (one byte permute fetches both columns'
+        // scores against this row's base); "Mp == 0" is the sign of Mp - 1 (Mp >= 0).  Mb = M + 128 where the cell is alive, 0 where not:
+        // the bias goes into the constants below, and a dead cell's -128 loses every maximum it enters just as its 0 would (E >= 0).
         const uint32_t Mp = ehh, e = ehe;
-        const uint32_t M = pk_mul(pk_minu(Mp, ONE), pk_add(Mp, sc)) & am;      // M = live && Mp ? Mp + sc : 0 (Mp >= 0)
-        const uint32_t tt = pk_max(pk_sub(M, OEI), 0u);
+        const uint32_t Mb = pk_add(Mp, pk_bytes(scp_lo, scp_hi, tb)) & am & ~pk_sra15(pk_sub(Mp, ONE));
+        const uint32_t M = pk_sub(Mb, BIAS);
+        const uint32_t tt = pk_max(pk_sub(Mb, OEIB), 0u);
         uint32_t P = pk_add(tt, je);                                           // U, then its inclusive prefix maximum per half
         P = pk_max(P, PK_DPP_ZERO(P, DPP_ROW_SHR(1), 0xf));
         P = pk_max(P, PK_DPP_ZERO(P, DPP_ROW_SHR(2), 0xf));
@@ -427,7 +431,7 @@ static __device__ ExtRes extend_wave_pk2(const DevIndex& ix, const MemOpt& opt, 
         // row maximum with the last column that attains it: one scan over (h, column) keys
         const int klo = (int)((uint32_t)(int)(int16_t)(h & 0xffffu) << 8) | lane, khi = (int)((uint32_t)((int)h >> 16) << 8) | jhi;
         const int best = wave_readlane(dpp_prefix_max(klo > khi ? klo : khi, -1), 63);
-        const uint32_t t2 = pk_max(pk_sub(M, OED), 0u);
+        const uint32_t t2 = pk_max(pk_sub(Mb, OEDB), 0u);
         const uint32_t en = pk_max(pk_sub(e, ED), t2);
         if (end > beg) { const int v = wave_readlane((int)h, (end - 1) & 63); h1 = ((end - 1) >> 6) ? v >> 16 : (int)(int16_t)(v & 0xffff); }
         // in-place row update: eh[pos1].h = h1i, eh[j+1].h = H(i,j) for the live columns, eh[j].e = E(i+1,j), eh[end].e = 0

@@ -16,7 +16,16 @@ DEV uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t
 DEV uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pk_s16_t, a), __builtin_bit_cast(pk_s16_t, b))); }
 DEV uint32_t pk_minu(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(pk_u16_t, a), __builtin_bit_cast(pk_u16_t, b))); }
 DEV uint32_t pk_mul(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (pk_u16_t)(__builtin_bit_cast(pk_u16_t, a) * __builtin_bit_cast(pk_u16_t, b))); }
-DEV uint32_t pk_sra15(uint32_t a) { return __builtin_bit_cast(uint32_t, (pk_s16_t)(__builtin_bit_cast(pk_s16_t, a) >> (pk_s16_t)15)); }   // 0xffff where the half is negative
+#if defined(__HIP_DEVICE_COMPILE__)
+// 0xffff where the half is negative.  As an instruction of its own: written as a vector shift the optimiser turns every use
+// of the mask into two 16-bit compares, two selects and a byte permute
+// (op_sel_hi:[0,1]: both halves take the shift count from the low half of the inline constant)
+DEV uint32_t pk_sra15(uint32_t a) { uint32_t r; asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }
+#else
+DEV uint32_t pk_sra15(uint32_t a) { return __builtin_bit_cast(uint32_t, (pk_s16_t)(__builtin_bit_cast(pk_s16_t, a) >> (pk_s16_t)15)); }
+#endif
+// bytes k and 4 + k of {lo, hi} as two unsigned 16-bit halves (v_perm_b32; k = 0..3, wave-uniform)
+DEV uint32_t pk_bytes(uint32_t lo, uint32_t hi, int k) { return __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)(4 + k) << 16 | (uint32_t)k); }
 #else
 DEV uint32_t pk_join(int lo, int hi) { return (uint32_t)(uint16_t)lo | (uint32_t)(uint16_t)hi << 16; }
 DEV int pk_lo_(uint32_t a) { return (int16_t)(a & 0xffffu); }
@@ -27,6 +36,7 @@ DEV uint32_t pk_max(uint32_t a, uint32_t b) { return pk_join(pk_lo_(a) > pk_lo_(
 DEV uint32_t pk_minu(uint32_t a, uint32_t b) { const uint32_t al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16; return (al < bl ? al : bl) | (ah < bh ? ah : bh) << 16; }
 DEV uint32_t pk_mul(uint32_t a, uint32_t b) { return ((a & 0xffffu) * (b & 0xffffu) & 0xffffu) | ((a >> 16) * (b >> 16) & 0xffffu) << 16; }
 DEV uint32_t pk_sra15(uint32_t a) { return (a & 0x8000u ? 0xffffu : 0u) | (a & 0x80000000u ? 0xffff0000u : 0u); }
+DEV uint32_t pk_bytes(uint32_t lo, uint32_t hi, int k) { return (lo >> (8 * k) & 0xffu) | (hi >> (8 * k) & 0xffu) << 16; }
 #endif
 // both halves = the 16 low bits of x / the two halves from two ints
 DEV uint32_t pk_both(int x) { return (uint32_t)(uint16_t)x * 0x10001u; }
