@@ -53,6 +53,7 @@ def load_lib():
     lib.jnibwa_free.argtypes = [ctypes.c_void_p]
     lib.bwamem_hip_set_device.argtypes = [ctypes.c_int]
     lib.bwamem_hip_index_replicas.argtypes = [ctypes.c_void_p]
+    lib.bwamem_hip_build_image.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p]
     lib.bwamem_hip_batch_wrap_device.restype = ctypes.c_void_p
     lib.bwamem_hip_batch_wrap_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p]
     lib.bwamem_hip_batch_align.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
@@ -456,6 +457,7 @@ def main():
             print("[bench] %6.1fs %s" % (time.time() - t0, msg), file=sys.stderr, flush=True)
 
     own_image = not args.image
+    t_index_build = None
     if args.image:
         img = args.image
         genome_desc = "reference image %s" % os.path.basename(img)
@@ -472,11 +474,23 @@ def main():
         tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
         img = os.path.join(tmpdir, "bwamem_hip_bench_%s.img" % (os.environ.get("MASTER_PORT", "p") + "_" + str(os.getppid()) if world > 1 else str(os.getpid())))
         if rank == 0:
-            import index_build_gpu as G
-            pieces = G.build_pieces(codes)
-            note("suffix array / BWT / occ / SA built on the device")
-            G.write_image(img, pieces, contigs)
-            del pieces
+            if os.environ.get("BENCH_TORCH_INDEX_BUILDER"):          # the independent torch builder (tests compare the two images)
+                import index_build_gpu as G
+                pieces = G.build_pieces(codes)
+                note("suffix array / BWT / occ / SA built on the device (torch builder)")
+                G.write_image(img, pieces, contigs)
+                del pieces
+            else:                                                     # the library's own builder (csrc/k_index.hip), codes handed over in host memory
+                h_codes = codes.cpu().numpy()
+                torch.cuda.empty_cache()
+                names = (ctypes.c_char_p * len(contigs))(*[n.encode() for n, _ in contigs])
+                lens = (ctypes.c_int64 * len(contigs))(*[l for _, l in contigs])
+                tb = time.time()
+                if lib.bwamem_hip_build_image(h_codes.ctypes.data, int(h_codes.size), len(contigs), names, lens, img.encode()) != 0:
+                    raise SystemExit("index build failed")
+                t_index_build = time.time() - tb
+                note("index image built by the library's device builder in %.1f s" % t_index_build)
+                del h_codes
             torch.cuda.empty_cache()
             note("index image written (%.2f GB)" % (os.path.getsize(img) / 1e9))
     if dist is not None:
@@ -674,7 +688,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32/int64", "data": "synthetic",
             "config": {"workload": "%d x %dbp %s synthetic reads per GPU vs %s, full index in HBM" % (R, L, "paired-end (2 x %d pairs)" % (R // 2) if args.paired else "single-end ONT-style (8 %% sub, 3 %% ins, 3 %% del)" if args.ont else "single-end", genome_desc),
-                       "reads_per_gpu": R, "read_len": L, "genome_bp": args.genome_bp, "genome": "image" if args.image else args.genome, "index_build_s": round(t_index, 1), "response_bytes": result_bytes,
+                       "reads_per_gpu": R, "read_len": L, "genome_bp": args.genome_bp, "genome": "image" if args.image else args.genome, "index_build_s": round(t_index, 1), "index_builder_s": round(t_index_build, 1) if t_index_build is not None else None, "response_bytes": result_bytes,
                        "parallelism": "read-sharded x%d, no collectives" % world, "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "paired_end": bool(args.paired), "insert_size_statistics": ("supplied " + args.pestat) if (args.paired and args.pestat) else ("inferred per call" if args.paired else None),
                        "value_is": "device-resident rate: request already in HBM when the timed region starts, response left in HBM (the bench contract); the rate through jnibwa_createAlignments itself is `host_to_host`"},
             "per_rank": {"reads_per_s": [R * args.steps / x for x in per_rank], "ms_per_step_min": min(per_rank) / args.steps * 1e3, "ms_per_step_max": max(per_rank) / args.steps * 1e3},

@@ -206,6 +206,14 @@ bool build_index_files(const std::string& fasta, const std::string& prefix, std:
     FastaPack fp;
     if (!pack_fasta(fasta, fp, err)) return false;
     const int64_t l = fp.p.l_pac;
+    const char* eb = getenv("BWAMEM_HIP_INDEX_BUILDER");
+    const bool force_host = eb && !strcmp(eb, "host"), force_dev = eb && !strcmp(eb, "device");
+    if (!force_host && device_index_available()) {
+        std::string derr;
+        if (device_index_pieces(fp.fwd, fp.p, &derr)) return write_index_files(fp.p, prefix, err);
+        if (force_dev) { if (err) *err = "device index builder: " + derr; return false; }
+        fprintf(stderr, "[bwamem_hip] device index builder failed (%s): building on the host\n", derr.c_str());
+    } else if (force_dev) { if (err) *err = "BWAMEM_HIP_INDEX_BUILDER=device but no HIP device is visible"; return false; }
     std::vector<uint8_t> text((size_t)(2 * l));
     for (int64_t i = 0; i < l; ++i) { text[i] = fp.fwd[i]; text[2 * l - 1 - i] = (uint8_t)(3 - fp.fwd[i]); }
     std::vector<int64_t> sa;

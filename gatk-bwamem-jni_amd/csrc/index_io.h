@@ -44,5 +44,10 @@ struct IndexPieces {
 };
 std::vector<uint8_t> image_from_pieces(const IndexPieces& p);
 
-// fasta -> <prefix>.{pac,ann,amb,bwt,sa}; replaces upstream bwa_idx_build (bwtindex.c)
+// fasta -> <prefix>.{pac,ann,amb,bwt,sa}; replaces upstream bwa_idx_build (bwtindex.c).  The suffix array, BWT, occ checkpoints
+// and SA samples are computed on the device when one is visible (k_index.hip), on the host otherwise or when
+// BWAMEM_HIP_INDEX_BUILDER=host; the files are byte-identical either way.
 bool build_index_files(const std::string& fasta, const std::string& prefix, std::string* err);
+// k_index.hip: is there a device to build on / the device half of the builder (fwd: one code 0..3 per forward-strand base)
+bool device_index_available();
+bool device_index_pieces(const std::vector<uint8_t>& fwd, IndexPieces& out, std::string* err);

@@ -1577,6 +1577,34 @@ void* jnibwa_getRefContigNames(bwaidx_t* pIdx, size_t* pBufSize)
     });
 }
 
+// Tooling (bench.py): an index image straight from base codes in host memory -- no FASTA, no five files in between -- built by
+// the device half of the index builder (k_index.hip).  codes: l_pac bytes 0..3; contigs by name and length.  0 = ok.
+int bwamem_hip_build_image(const uint8_t* codes, int64_t l_pac, int32_t n_contigs, const char* const* names, const int64_t* lens, const char* img_path)
+{
+    return guarded("bwamem_hip_build_image", -1, [&]() -> int {
+        if (!codes || l_pac <= 0 || n_contigs <= 0 || !names || !lens || !img_path) return -1;
+        IndexPieces p;
+        int64_t off = 0;
+        for (int i = 0; i < n_contigs; ++i) {
+            ContigInfo c; c.offset = off; c.len = (int32_t)lens[i]; c.n_ambs = 0; c.gi = 0; c.is_alt = 0; c.name = names[i]; c.anno = "";
+            p.contigs.push_back(c); off += lens[i];
+        }
+        if (off != l_pac) return -1;
+        p.l_pac = l_pac; p.seed = 11;
+        std::vector<uint8_t> fwd(codes, codes + l_pac);
+        p.pac.assign((size_t)(l_pac / 4 + 1), 0);
+        for (int64_t i = 0; i < l_pac; ++i) p.pac[i >> 2] |= (uint8_t)((fwd[i] & 3) << ((~i & 3) << 1));
+        std::string err;
+        if (!device_index_pieces(fwd, p, &err)) { fprintf(stderr, "[bwamem_hip] device index builder: %s\n", err.c_str()); return -1; }
+        std::vector<uint8_t>().swap(fwd);
+        const std::vector<uint8_t> img = image_from_pieces(p);
+        FILE* fp = fopen(img_path, "wb");
+        if (!fp) return -1;
+        const bool ok = fwrite(img.data(), 1, img.size(), fp) == img.size();
+        return fclose(fp) == 0 && ok ? 0 : -1;
+    });
+}
+
 int bwamem_hip_index_contig_lengths(bwaidx_t* idx, int64_t* lens, int cap)
 {
     if (!idx) return -1;

@@ -69,6 +69,10 @@ int bwamem_hip_index_replicas(bwaidx_t* idx);
 int bwamem_hip_index_contig_lengths(bwaidx_t* idx, int64_t* lens, int cap);
 int bwamem_hip_index_unpack_pac(bwaidx_t* idx, int64_t start, int64_t n, void* d_dst);
 
+/* Tooling (bench.py): an index image straight from base codes (0..3, one per byte, host memory) and a contig table, built on
+ * the device (the same builder jnibwa_createReferenceIndex uses when a device is visible).  0 = ok. */
+int bwamem_hip_build_image(const uint8_t* codes, int64_t l_pac, int32_t n_contigs, const char* const* names, const int64_t* lens, const char* img_path);
+
 typedef struct bwamem_batch_s bwamem_batch_t; /* a request resident in HBM */
 
 /* upload a request buffer (same wire format as pSeq above); the host buffer is left untouched */

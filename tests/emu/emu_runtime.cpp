@@ -129,3 +129,10 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 }
 
 } // namespace emu
+
+// k_index.hip (the device half of the index builder, rocPRIM sorts) is not part of the emulation build: the host builder runs
+#include <string>
+#include <vector>
+#include "index_io.h"
+bool device_index_available() { return false; }
+bool device_index_pieces(const std::vector<uint8_t>&, IndexPieces&, std::string* err) { if (err) *err = "no device in the emulation build"; return false; }
