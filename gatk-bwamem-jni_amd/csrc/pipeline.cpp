@@ -1422,6 +1422,8 @@ template <typename R, typename F> static R guarded(const char* what, R fail, F&&
     return fail;
 }
 
+const std::vector<ContigInfo>& bwamem_index_contigs(const bwaidx_t* idx) { return idx->h.contigs; }     // (sam_writer.cpp)
+
 extern "C" {
 
 int bwamem_hip_set_device(int device) { g_device = device; g_device_explicit = true; return hipSetDevice(device) == hipSuccess ? 0 : -1; }

@@ -102,6 +102,13 @@ size_t bwamem_hip_batch_result_bytes(const bwamem_batch_t* b);
 int bwamem_hip_batch_download(bwamem_batch_t* b, void* dst);
 void bwamem_hip_batch_free(bwamem_batch_t* b);
 
+/* SAM text on the native side (additive).  pSeq = the request handed to jnibwa_createAlignments,
+ * response = what it returned.  One line per record, layout described in csrc/sam_writer.cpp; readNames = nSeqs names or NULL
+ * ("r<index>", paired: "p<pair index>"); paired = the call carried MEM_F_PE.  Both return malloc'ed, NUL-terminated text (free
+ * with jnibwa_free) or NULL when the response does not parse against the request. */
+char* bwamem_hip_sam_header(bwaidx_t* idx, size_t* pBytes);
+char* bwamem_hip_response_to_sam(bwaidx_t* idx, const char* pSeq, const void* response, size_t responseBytes, const char* const* readNames, int paired, size_t* pBytes);
+
 typedef struct {
     /* algorithmic counters */
     uint64_t n_reads, n_ext, n_lf, n_sa, n_dp_cells;
