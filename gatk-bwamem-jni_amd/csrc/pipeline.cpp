@@ -911,7 +911,8 @@ static void append_stretch(CallPipe& pp, const ReqChunk& rc, const MemOpt& opt, 
     // the larger tile is for short reads in repeats; long reads carry thousands of seeds each whatever the reference, and twice
     // their workspaces does not fit four times next to the index
     { const uint32_t n = rc.r1 - rc.r0; if (n && (rc.h_off[n] - rc.h_off[0]) / n > 1000) tile_scale = 1; }
-    if (even) tile_scale = 1;               // paired-end: the pairing stage is one lane per pair and lasts as long as its heaviest pair; more tiles in flight
+    // (paired-end calls took the standard tile while the pairing stage was one lane per pair and lasted as long as its heaviest pair;
+    // with the incremental list maintenance and a wavefront per heavy pair the larger tile pays here too: human-like genome + 3 %)
                                             // hide that better than larger ones amortise it (human-like genome, 4 M reads: 0.45 M reads/s with twice the reads per tile, 0.69 M without)
     std::vector<TileSpec> tiles;
     plan_tiles(rc, opt, even, false, tile_scale, tiles);
