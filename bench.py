@@ -673,7 +673,7 @@ def main():
         # FETCH_SIZE measured by tests/gpu_units/pmc_seed.sh on this workload (committed summary, see profiles/README.md)
         # is scaled to this launch's extension count
         traffic, traffic_note = None, None
-        for name in ("r02_pmc_k_seed.json", "r01_pmc_k_seed.json"):
+        for name in ("r03_pmc_k_seed.json", "r02_pmc_k_seed.json", "r01_pmc_k_seed.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pmc = json.load(f)

@@ -19,14 +19,12 @@ DEV uint32_t mask16(int n)                                  // bit-plane mask of
     n = n < 0 ? 0 : n > 16 ? 16 : n;
     return (uint32_t)(0x5555555500000000ull >> (n << 1));
 }
-// per word: the symbols whose low bit, high bit, and both bits are set among the masked ones (C = low only, G = high only, T = both:
-// the three classes follow from these sums by two subtractions per block instead of two and-nots per word)
-DEV void cnt_word_m(uint32_t x, uint32_t m, uint32_t& n_lo, uint32_t& n_hi, uint32_t& n_both)
+DEV void cnt_word_m(uint32_t x, uint32_t m, uint32_t& c1, uint32_t& c2, uint32_t& c3)
 {
     const uint32_t lo = x & m, hi = (x >> 1) & m;
-    n_both += __popc(hi & lo);
-    n_hi += __popc(hi);
-    n_lo += __popc(lo);
+    c3 += __popc(hi & lo);
+    c2 += __popc(hi & ~lo);
+    c1 += __popc(~hi & lo);
 }
 // bwt_extend for one symbol, both directions through one code path (cf. extend_one / occ4 in dev_common.h; this form
 // always issues the loads of both blocks at once and never forms the A counts from the block position: the counts of
@@ -48,7 +46,6 @@ DEV void extend_sm(const DevIndex& ix, uint64_t x0, uint64_t x1, uint64_t size, 
     cnt_word_m(sk.y, mask16(nk - 16), a1, a2, a3);  cnt_word_m(sl.y, mask16(nl - 16), b1, b2, b3);
     cnt_word_m(sk.z, mask16(nk - 32), a1, a2, a3);  cnt_word_m(sl.z, mask16(nl - 32), b1, b2, b3);
     cnt_word_m(sk.w, mask16(nk - 48), a1, a2, a3);  cnt_word_m(sl.w, mask16(nl - 48), b1, b2, b3);
-    a1 -= a3; a2 -= a3; b1 -= b3; b2 -= b3;                // (low, high, both) -> (C, G, T)
     // occ(k, b) and occ(l, b) for b = C, G, T
     const uint64_t tk1 = ((uint64_t)(ck.w & 0xffu) << 32 | ck.x) + a1, tk2 = ((uint64_t)(ck.w >> 8 & 0xffu) << 32 | ck.y) + a2, tk3 = ((uint64_t)(ck.w >> 16 & 0xffu) << 32 | ck.z) + a3;
     const uint64_t tl1 = ((uint64_t)(cl.w & 0xffu) << 32 | cl.x) + b1, tl2 = ((uint64_t)(cl.w >> 8 & 0xffu) << 32 | cl.y) + b2, tl3 = ((uint64_t)(cl.w >> 16 & 0xffu) << 32 | cl.z) + b3;

@@ -160,6 +160,7 @@ struct Workspace {
 // Interval lists of one seeding chunk (single-end path): k_seed runs over chunks of a few million reads -- several
 // tiles -- because its running time is bounded below by the slowest read of a launch; the tiles of the chunk then
 // point their TileView at slices of these arrays.
+#define SEED_STORES_MAX 4
 struct SeedStore {
     DevBuf intv, n_intv, intv_seed_off, n_seeds, l_rep;
     int cap = 0;                      // intervals per read
@@ -238,7 +239,7 @@ struct bwaidx_s {
     Workspace ws;
     std::vector<Workspace*> extra_ws;   // further tiles in flight (one stream + host thread each)
     Workspace seed_ws;                  // stream, flags and spill area of the seeding stage (single-end path)
-    SeedStore seed_store[2];            // double-buffered: chunk c+1 is seeded while the tiles of chunk c run
+    SeedStore seed_store[SEED_STORES_MAX];   // a ring: chunk c + n is seeded while the tiles of chunk c run (n = seed_stores() - 1)
     CapHints hints;
     std::vector<ReqBuf*> req_bufs;      // request stretches of a streamed call (jnibwa_createAlignments)
     hipStream_t up_stream = nullptr;    // their uploads
@@ -418,7 +419,7 @@ static void free_index(bwaidx_s* ix)
     for (DevBuf* b : all) b->release();
     ix->ws.release();
     ix->seed_ws.release();
-    ix->seed_store[0].release(); ix->seed_store[1].release();
+    for (SeedStore& st : ix->seed_store) st.release();
     for (Workspace* w : ix->extra_ws) { w->release(); delete w; }
     ix->extra_ws.clear();
     for (ReqBuf* r : ix->req_bufs) { r->release(); delete r; }
@@ -1033,6 +1034,10 @@ static bool run_pipeline(bwaidx_s* ix, const MemOpt& opt, bwamem_batch_s* b, boo
     while ((int)ix->extra_ws.size() < n_workers - 1) ix->extra_ws.push_back(new Workspace());
     // BWAMEM_HIP_SEED_AHEAD=0 serialises the seeding behind the tiles (isolated kernel timings)
     const bool seed_ahead = !(getenv("BWAMEM_HIP_SEED_AHEAD") && atoi(getenv("BWAMEM_HIP_SEED_AHEAD")) == 0);
+    // interval stores in the ring (BWAMEM_HIP_SEED_STORES, 2 .. SEED_STORES_MAX): with two the seeding kernel waits for the tiles of the
+    // chunk before last, and a 10 M-read call has no seeding on the device for a third of its time
+    const char* env_ns = getenv("BWAMEM_HIP_SEED_STORES");
+    const int n_stores = std::max(2, std::min<int>(SEED_STORES_MAX, env_ns ? atoi(env_ns) : 3));
     auto fail = [&]() { pp.fail(); b->sink.abort(); };
     auto producer = [&]() {
         bool ok = false;
@@ -1058,15 +1063,15 @@ static bool run_pipeline(bwaidx_s* ix, const MemOpt& opt, bwamem_batch_s* b, boo
                     std::unique_lock<std::mutex> lk(pp.mu);
                     pp.cv.wait(lk, [&] { return pp.failed || c < pp.chunks.size() || pp.produced_all; });
                     if (pp.failed || c >= pp.chunks.size()) break;
-                    pp.cv.wait(lk, [&] {                                       // the store of chunk c was last used by chunk c-2
+                    pp.cv.wait(lk, [&] {                                       // the store of chunk c was last used by chunk c - n_stores
                         if (pp.failed) return true;
-                        for (size_t k = 0; k < c; ++k) if ((k + 2 <= c || !seed_ahead) && pp.chunks[k].tiles_left != 0) return false;
+                        for (size_t k = 0; k < c; ++k) if ((k + (size_t)n_stores <= c || !seed_ahead) && pp.chunks[k].tiles_left != 0) return false;
                         return true;
                     });
                     if (pp.failed) break;
                     ch = pp.chunks[c];
                 }
-                const bool ok = seed_chunk(ix, opt, ch, ix->seed_store[c & 1], intv_cap_scale);
+                const bool ok = seed_chunk(ix, opt, ch, ix->seed_store[c % (size_t)n_stores], intv_cap_scale);
                 { std::lock_guard<std::mutex> lk(pp.mu); pp.chunks[c].state = ok ? 1 : -1; }
                 if (!ok) { fail(); break; }
                 pp.cv.notify_all();
@@ -1090,7 +1095,7 @@ static bool run_pipeline(bwaidx_s* ix, const MemOpt& opt, bwamem_batch_s* b, boo
                     if (pp.failed || pp.chunks[c].state < 0) break;
                     chunk_r0 = pp.chunks[c].r0;
                 }
-                const bool ok = fn(w, i, sp, ix->seed_store[c & 1], chunk_r0);
+                const bool ok = fn(w, i, sp, ix->seed_store[c % (size_t)n_stores], chunk_r0);
                 { std::lock_guard<std::mutex> lk(pp.mu); --pp.chunks[c].tiles_left; }
                 pp.cv.notify_all();
                 if (!ok) { fail(); break; }
