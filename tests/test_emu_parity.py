@@ -301,7 +301,7 @@ seqs = []
 for blk in open(%r).read().split(">")[1:]:
     name, _, body = blk.partition("\n")
     seqs.append((name.strip(), body.replace("\n", "").encode()))
-reads = B.simulate_reads(seqs, 3, length=800, seed=5, sub=0.06, indel=0.02)
+reads = B.simulate_reads(seqs, 2, length=800, seed=5, sub=0.06, indel=0.02)
 h, ho = emu.open_index(%r), orc.open_index(%r)
 opts = emu.default_options()
 req = B.pack_request(reads)

@@ -97,7 +97,7 @@ def _check_extend(units, oracle, n_cases, max_q):
             assert list(got) == [ws, want[0], want[1], want[2], want[3], want[4]], (it, force_lds, qlen, tlen, kw, w, zdrop, h0)
 
 
-def _check_extend_16bit_boundary(units, oracle):
+def _check_extend_16bit_boundary(units, oracle, qlens=(126, 100, 65)):
     """the packed form of the two-chunk extension keeps its scores in 16-bit halves and must hand a query over to the 32-bit
     form when they could not fit (k_extend.hip: extend_pk2_ok, h0 + qlen * max score + 130 e_ins < 30000): match scores of 127
     and initial scores on either side of that line, with mismatches and a gap so that the rows are real DP"""
@@ -105,7 +105,7 @@ def _check_extend_16bit_boundary(units, oracle):
     oext.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p] * 5
     rng = np.random.default_rng(5)
     base_opts = oracle.default_options()
-    for qlen in (126, 100, 65):
+    for qlen in qlens:
         for e_ins in (1, 3):
             edge = 30000 - qlen * 127 - 130 * e_ins
             for h0 in (edge - 1, edge, edge + 7, 200):
@@ -138,8 +138,8 @@ def test_units_emu_sort(oracle):
 
 
 def test_units_emu_extend(oracle):
-    _check_extend(_load("emu"), oracle, 60, 230)
-    _check_extend_16bit_boundary(_load("emu"), oracle)
+    _check_extend(_load("emu"), oracle, 40, 230)
+    _check_extend_16bit_boundary(_load("emu"), oracle, qlens=(126, 65))
 
 
 @pytest.mark.gpu
