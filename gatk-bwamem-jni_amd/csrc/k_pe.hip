@@ -445,6 +445,38 @@ __global__ void __launch_bounds__(64) k_pe_rescue_sw(DevIndex ix, MemOpt opt, Ti
     if (err) atomicOr(tv.err, err);
 }
 
+// the same for byte-mode jobs of up to NSEG segments, eight per wavefront (two per 16-lane group, one per half of every register:
+// sw_common.h: sw_core_wave8_u8); leaves every other job alone
+template <int NSEG>
+__global__ void __launch_bounds__(64) k_pe_rescue_sw8(DevIndex ix, MemOpt opt, TileView tv, const RescueJob* jobs, const int32_t* counter, int cap, KswR* results, int cap_b)
+{
+    HIP_DYNAMIC_SHARED(uint64_t, blists)
+    const int lane = threadIdx.x;
+    if (tv.err[0] & ERR_RESCUE_CAP) return;
+    const int n = *counter < cap ? *counter : cap;
+    if ((int)blockIdx.x * 8 >= n) return;
+    SwPair P;
+    int job[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        job[h] = blockIdx.x * 8 + (lane >> 4) * 2 + h;
+        RescueJob jb; jb.rb = 0; jb.read = 0; jb.tag = 0; jb.l_ms = 0; jb.is_rev = 0; jb.tlen = 0; jb.xtra = 0; jb.q_off = 0; jb.pad_ = 0;
+        if (job[h] < n) jb = jobs[job[h]];
+        const int slen = (jb.l_ms + 15) / 16;
+        P.on[h] = job[h] < n && (jb.xtra & KSW_XBYTE) != 0 && slen > 0 && slen <= NSEG;
+        P.I[h].ms = tv.seq + tv.seq_off[jb.read] + jb.q_off; P.I[h].l_ms = jb.l_ms; P.I[h].is_rev = jb.is_rev; P.I[h].qrev = 0; P.I[h].t0 = jb.rb; P.I[h].trev = 0;
+        P.qlen[h] = jb.l_ms; P.tlen[h] = jb.tlen; P.xtra[h] = jb.xtra;
+    }
+    if (__ballot(P.on[0] || P.on[1]) == 0ull) return;
+    SwLds L; L.b = blists; L.cap_b = cap_b;
+    int err = 0;
+    KswR R[2];
+    sw_align2_wave8_u8<NSEG>(ix, opt, P, L, lane, err, R);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) if (P.on[h] && (lane & 15) == 0) results[job[h]] = R[h];
+    if (err) atomicOr(tv.err, err);
+}
+
 // mem_matesw for one anchor of a heavy pair, by the wavefront (uniform arguments; see matesw)
 DEV void matesw_wave(const DevIndex& ix, const MemOpt& opt, SwScratch& W, const MemPestat* pes, const AlnReg& a,
                      int l_ms, const uint8_t* ms, int& n_ma, AlnReg* ma, int cap_ma, int& err,
@@ -850,7 +882,11 @@ void launch_sw_jobs(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const
     // (seed re-scoring windows of long reads, 250 bp mates), 8 bases per segment, eight alignments per wave: up to 10, 11..16,
     // 17..25, 26..32 segments.
 #define SW_LAUNCH(LO, HI, GW) hipLaunchKernelGGL((k_pe_rescue_sw<LO, HI, GW>), dim3((cap + 64 / GW - 1) / (64 / GW)), dim3(64), (size_t)(64 / GW) * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b)
-    SW_LAUNCH(0, 10, 16);
+    // byte mode up to 10 segments (150 bp mates): two alignments per lane in packed halves, eight per wave; BWAMEM_HIP_SW_PACKED=0: the
+    // one-value-per-register form (tests compare the two)
+    static const bool packed = []{ const char* e = getenv("BWAMEM_HIP_SW_PACKED"); return !(e && atoi(e) == 0); }();
+    if (packed) hipLaunchKernelGGL((k_pe_rescue_sw8<10>), dim3((cap + 7) / 8), dim3(64), (size_t)8 * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b);
+    else SW_LAUNCH(0, 10, 16);
     if (max_qlen > 160) SW_LAUNCH(10, 16, 16);
     SW_LAUNCH(0, 10, 8);
     if (max_qlen > 80) SW_LAUNCH(10, 16, 8);

@@ -4,6 +4,7 @@
 // second-best bookkeeping) depend on the striped layout, so the layout is kept lane by lane with scalar arithmetic.
 #pragma once
 #include "dev_common.h"
+#include "pk16.h"
 
 // ------------------------------------------------------------------ striped local SW (ksw_align2)
 #define KSW_XBYTE  0x10000
@@ -298,4 +299,193 @@ DEV KswR sw_align2_wave4(const DevIndex& ix, const MemOpt& opt, SwIn I, bool on,
     KswR rr = sw_core_wave4<NSEG, GW>(ix, opt, I, again, size, again ? r.qe + 1 : 0, tlen, KSW_XSTOP | r.score, W, lane, err);
     if (again && r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
     return r;
+}
+
+
+// ------------------------------------------------------------------ byte mode, two alignments per lane
+// The byte-mode kernel above keeps one 8-bit value per 32-bit register.  Here every register carries two alignments, one per
+// 16-bit half (pk16.h): group g of 16 lanes runs alignments 2g (low halves) and 2g + 1 (high halves), eight per wavefront, and
+// one stream of packed instructions computes both -- unsigned saturation at 255 is a packed minimum, saturation at 0 the clamp
+// bit of the packed subtraction, and the scores of both alignments against their own target bases come out of one byte permute
+// (the lane keeps score + shift for the four target bases as the four bytes of a word per segment and alignment).  Everything
+// the two alignments do not share (target length, stop, the row-maxima list, the best row) is kept per half.  The lazy-F loop
+// runs whole passes until no half of the wave asks for more: a pass past an alignment's own fixed point changes nothing (at the
+// fixed point F is below H - o - e everywhere, which is what the pass would take the maximum with).
+struct SwPair { SwIn I[2]; bool on[2]; int qlen[2], tlen[2], xtra[2]; };
+
+template <int NSEG>
+static __device__ __attribute__((noinline)) void sw_core_wave8_u8(const DevIndex& ix, const MemOpt& opt, const SwPair& P, const SwLds& W, int lane, int& err, KswR R[2])
+{
+    const int g = lane >> 4, sl = lane & 15;
+    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+    int lo = 127, hi = 0;
+    for (int a = 0; a < 25; ++a) { if (opt.mat[a] < lo) lo = opt.mat[a]; if (opt.mat[a] > hi) hi = opt.mat[a]; }
+    const int shift = (256 - (lo & 0xff)) & 0xff, qmax = hi;
+    const uint32_t SHIFT = pk_both(shift), C255 = pk_both(255), OED = pk_both(o_del + e_del), ED = pk_both(e_del), OEI = pk_both(o_ins + e_ins), EI = pk_both(e_ins);
+    int slen[2], n_b[2] = { 0, 0 }, te[2] = { -1, -1 }, gmax[2] = { 0, 0 }, minsc[2], endsc[2];
+    bool stop[2];
+    uint64_t* bl[2];
+    PacCache pc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        slen[h] = P.on[h] ? (P.qlen[h] + 15) / 16 : 0;
+        minsc[h] = (P.xtra[h] & KSW_XSUBO) ? P.xtra[h] & 0xffff : 0x10000;
+        endsc[h] = (P.xtra[h] & KSW_XSTOP) ? P.xtra[h] & 0xffff : 0x10000;
+        stop[h] = !P.on[h];
+        bl[h] = W.b + (size_t)(g * 2 + h) * W.cap_b;
+        pc[h].w = -1; pc[h].v = 0;
+        R[h].score = 0; R[h].te = R[h].qe = R[h].score2 = R[h].te2 = R[h].tb = R[h].qb = -1;
+    }
+    const ScoreTab ST = score_tab(opt);
+    uint32_t H0[NSEG], H1[NSEG], E[NSEG], Hmax[NSEG], SA[NSEG], SB[NSEG], sm[NSEG];
+#pragma unroll
+    for (int j = 0; j < NSEG; ++j) {
+        H0[j] = H1[j] = E[j] = Hmax[j] = 0;
+        uint32_t sw[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pos = j + sl * slen[h];
+            const bool pad = !(P.on[h] && j < slen[h] && pos < P.qlen[h]);
+            uint32_t sp; int sn;
+            score_lane(ST, pad ? 4 : sw_q(P.I[h], pos), sp, sn);
+            // score + shift per target base as unsigned bytes; a pad position scores 0 against everything
+            uint32_t w = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) w |= (uint32_t)(((pad ? 0 : (int)(int8_t)(sp >> (b << 3))) + shift) & 0xff) << (b << 3);
+            sw[h] = w;
+        }
+        SA[j] = sw[0]; SB[j] = sw[1];
+        sm[j] = (j < slen[0] ? 0xffffu : 0u) | (j < slen[1] ? 0xffff0000u : 0u);
+    }
+    for (int i = 0; ; ++i) {
+        bool run[2];
+        uint32_t tb[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            run[h] = !stop[h] && i < P.tlen[h];
+            tb[h] = run[h] ? (uint32_t)ref_base2_c(ix, pc[h], P.I[h].t0 + (i < P.I[h].trev ? P.I[h].trev - 1 - i : i)) : 0u;
+        }
+        if (__ballot(run[0] || run[1]) == 0ull) break;
+        const uint32_t runm = (run[0] ? 0xffffu : 0u) | (run[1] ? 0xffff0000u : 0u);
+        uint32_t f = 0, mx = 0, hlast = 0;
+#pragma unroll
+        for (int j = 0; j < NSEG; ++j) {
+            if (j == slen[0] - 1) hlast = (hlast & 0xffff0000u) | (H0[j] & 0xffffu);
+            if (j == slen[1] - 1) hlast = (hlast & 0xffffu) | (H0[j] & 0xffff0000u);
+        }
+        uint32_t h = (uint32_t)__shfl_up((int)hlast, 1);
+        if (sl == 0) h = 0;
+#pragma unroll
+        for (int j = 0; j < NSEG; ++j) {                    // (segments beyond an alignment's own are masked, not skipped: no branches in the row)
+            const uint32_t sc = pk_bytes2(SA[j], SB[j], tb[0], tb[1]);
+            uint32_t hh = pk_minu(pk_add(h, sc), C255);
+            hh = pk_subs(hh, SHIFT);
+            hh = pk_max(hh, E[j]);
+            hh = pk_max(hh, f) & sm[j];
+            mx = pk_max(mx, hh);
+            H1[j] = hh;
+            const uint32_t t = pk_subs(hh, OED);
+            E[j] = pk_max(pk_subs(E[j], ED), t);
+            const uint32_t t2 = pk_subs(hh, OEI);
+            f = pk_max(pk_subs(f, EI), t2);
+            h = H0[j];
+        }
+        for (int k = 0; k < 16; ++k) {                      // lazy-F across segment boundaries, whole passes
+            uint32_t fs = (uint32_t)__shfl_up((int)f, 1);
+            if (sl == 0) fs = 0;
+            f = fs;
+            uint32_t more = 0;
+#pragma unroll
+            for (int j = 0; j < NSEG; ++j) {
+                uint32_t hh = pk_max(H1[j], f);
+                H1[j] = hh;
+                hh = pk_subs(hh, OEI);
+                f = pk_subs(f, EI);
+                more |= pk_subs(f, hh) & sm[j];
+            }
+            if (__ballot((more & runm) != 0) == 0ull) break;
+        }
+        uint32_t imax = mx;
+        for (int o = 8; o > 0; o >>= 1) imax = pk_max(imax, (uint32_t)__shfl_xor((int)imax, o));
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int im = pk_half(imax, hf);
+            if (run[hf] && im >= minsc[hf]) {
+                if (n_b[hf] == 0 || (int32_t)bl[hf][n_b[hf] - 1] + 1 != i) {
+                    if (n_b[hf] >= W.cap_b) { err |= ERR_SCRATCH; stop[hf] = true; }
+                    else { if (sl == 0) bl[hf][n_b[hf]] = (uint64_t)im << 32 | (uint32_t)i; ++n_b[hf]; }
+                } else if ((int)(bl[hf][n_b[hf] - 1] >> 32) < im) { if (sl == 0) bl[hf][n_b[hf] - 1] = (uint64_t)im << 32 | (uint32_t)i; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int im = pk_half(imax, hf);
+            if (run[hf] && !stop[hf] && im > gmax[hf]) {
+                gmax[hf] = im; te[hf] = i;
+                const uint32_t hm = hf ? 0xffff0000u : 0xffffu;
+#pragma unroll
+                for (int j = 0; j < NSEG; ++j) Hmax[j] = (Hmax[j] & ~hm) | (H1[j] & hm);
+                if (gmax[hf] + shift >= 255 || gmax[hf] >= endsc[hf]) stop[hf] = true;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NSEG; ++j) { const uint32_t t = H0[j]; H0[j] = H1[j]; H1[j] = t; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        KswR& r = R[hf];
+        r.score = gmax[hf] + shift < 255 ? gmax[hf] : 255;
+        r.te = te[hf];
+        int best = -1, bq = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < NSEG; ++j) {
+            if (j < slen[hf]) {
+                const int v = pk_half(Hmax[j], hf), pos = j + sl * slen[hf];
+                if (v > best || (v == best && pos < bq)) { best = v; bq = pos; }
+            }
+        }
+        for (int o = 8; o > 0; o >>= 1) {
+            const int ub = __shfl_xor(best, o), uq = __shfl_xor(bq, o);
+            if (ub > best || (ub == best && uq < bq)) { best = ub; bq = uq; }
+        }
+        if (P.on[hf] && r.score != 255) {
+            r.qe = bq;
+            if (n_b[hf] > 0) {
+                int i = (r.score + qmax - 1) / qmax;
+                const int low = te[hf] - i, high = te[hf] + i;
+                for (i = 0; i < n_b[hf]; ++i) {
+                    const int e = (int32_t)bl[hf][i];
+                    if ((e < low || e > high) && (int)(bl[hf][i] >> 32) > r.score2) { r.score2 = (int)(bl[hf][i] >> 32); r.te2 = e; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ksw_align2 in byte mode for the eight alignments of a wavefront (two per group of 16 lanes); P per lane, uniform within a group
+template <int NSEG>
+DEV void sw_align2_wave8_u8(const DevIndex& ix, const MemOpt& opt, SwPair P, const SwLds& W, int lane, int& err, KswR R[2])
+{
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { P.I[h].qrev = 0; P.I[h].trev = 0; }
+    sw_core_wave8_u8<NSEG>(ix, opt, P, W, lane, err, R);
+    SwPair Q = P;
+    bool again[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        again[h] = P.on[h] && !((P.xtra[h] & KSW_XSTART) == 0 || ((P.xtra[h] & KSW_XSUBO) && R[h].score < (P.xtra[h] & 0xffff)));
+        Q.on[h] = again[h];
+        Q.I[h].qrev = R[h].qe + 1; Q.I[h].trev = R[h].te + 1;
+        Q.qlen[h] = again[h] ? R[h].qe + 1 : 0;
+        Q.xtra[h] = KSW_XSTOP | R[h].score;
+    }
+    if (__ballot(again[0] || again[1]) == 0ull) return;
+    KswR RR[2];
+    sw_core_wave8_u8<NSEG>(ix, opt, Q, W, lane, err, RR);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (again[h] && R[h].score == RR[h].score) { R[h].tb = R[h].te - RR[h].te; R[h].qb = R[h].qe - RR[h].qe; }
 }
