@@ -162,7 +162,7 @@ static __device__ __attribute__((noinline)) KswR sw_core_wave4(const DevIndex& i
     int lo = 127, hi = 0;
     for (int a = 0; a < 25; ++a) { if (opt.mat[a] < lo) lo = opt.mat[a]; if (opt.mat[a] > hi) hi = opt.mat[a]; }
     const int shift = (256 - (lo & 0xff)) & 0xff, qmax = hi;
-    int n_b = 0, te = -1, gmax = 0;
+    int n_b = 0, te = -1, gmax = 0, last_i = -2, last_sc = 0;
     const int minsc = (xtra & KSW_XSUBO) ? xtra & 0xffff : 0x10000;
     const int endsc = (xtra & KSW_XSTOP) ? xtra & 0xffff : 0x10000;
     const bool la = on && sl < p;                           // this lane is one of upstream's vector lanes of a live group
@@ -235,13 +235,14 @@ static __device__ __attribute__((noinline)) KswR sw_core_wave4(const DevIndex& i
         int imax = la && run ? mx : 0;
         for (int o = GW / 2; o > 0; o >>= 1) { const int u = __shfl_xor(imax, o); imax = imax > u ? imax : u; }
         imax = __shfl(imax, g * GW);
+        // the list of row maxima: a row next to the last listed one only replaces it when it is higher.  The last entry is kept
+        // in registers by every lane (the list itself is only read after the loop), so the rows need no barrier
         if (run && imax >= minsc) {
-            if (n_b == 0 || (int32_t)bl[n_b - 1] + 1 != i) {
+            if (n_b == 0 || last_i + 1 != i) {
                 if (n_b >= W.cap_b) { err |= ERR_SCRATCH; stop = true; }
-                else { if (sl == 0) bl[n_b] = (uint64_t)imax << 32 | (uint32_t)i; ++n_b; }
-            } else if ((int)(bl[n_b - 1] >> 32) < imax) { if (sl == 0) bl[n_b - 1] = (uint64_t)imax << 32 | (uint32_t)i; }
+                else { if (sl == 0) bl[n_b] = (uint64_t)imax << 32 | (uint32_t)i; ++n_b; last_i = i; last_sc = imax; }
+            } else if (last_sc < imax) { if (sl == 0) bl[n_b - 1] = (uint64_t)imax << 32 | (uint32_t)i; last_i = i; last_sc = imax; }
         }
-        __syncthreads();
         if (run && !stop && imax > gmax) {
             gmax = imax; te = i;
 #pragma unroll
@@ -322,7 +323,7 @@ static __device__ __attribute__((noinline)) void sw_core_wave8_u8(const DevIndex
     for (int a = 0; a < 25; ++a) { if (opt.mat[a] < lo) lo = opt.mat[a]; if (opt.mat[a] > hi) hi = opt.mat[a]; }
     const int shift = (256 - (lo & 0xff)) & 0xff, qmax = hi;
     const uint32_t SHIFT = pk_both(shift), C255 = pk_both(255), OED = pk_both(o_del + e_del), ED = pk_both(e_del), OEI = pk_both(o_ins + e_ins), EI = pk_both(e_ins);
-    int slen[2], n_b[2] = { 0, 0 }, te[2] = { -1, -1 }, gmax[2] = { 0, 0 }, minsc[2], endsc[2];
+    int slen[2], n_b[2] = { 0, 0 }, te[2] = { -1, -1 }, gmax[2] = { 0, 0 }, minsc[2], endsc[2], last_i[2] = { -2, -2 }, last_sc[2] = { 0, 0 };
     bool stop[2];
     uint64_t* bl[2];
     PacCache pc[2];
@@ -387,7 +388,7 @@ static __device__ __attribute__((noinline)) void sw_core_wave8_u8(const DevIndex
             const uint32_t t = pk_subs(hh, OED);
             E[j] = pk_max(pk_subs(E[j], ED), t);
             const uint32_t t2 = pk_subs(hh, OEI);
-            f = pk_max(pk_subs(f, EI), t2);
+            f = (pk_max(pk_subs(f, EI), t2) & sm[j]) | (f & ~sm[j]);       // (F leaves an alignment's last segment unchanged by the masked ones behind it)
             h = H0[j];
         }
         for (int k = 0; k < 16; ++k) {                      // lazy-F across segment boundaries, whole passes
@@ -400,7 +401,7 @@ static __device__ __attribute__((noinline)) void sw_core_wave8_u8(const DevIndex
                 uint32_t hh = pk_max(H1[j], f);
                 H1[j] = hh;
                 hh = pk_subs(hh, OEI);
-                f = pk_subs(f, EI);
+                f = (pk_subs(f, EI) & sm[j]) | (f & ~sm[j]);
                 more |= pk_subs(f, hh) & sm[j];
             }
             if (__ballot((more & runm) != 0) == 0ull) break;
@@ -410,14 +411,13 @@ static __device__ __attribute__((noinline)) void sw_core_wave8_u8(const DevIndex
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int im = pk_half(imax, hf);
-            if (run[hf] && im >= minsc[hf]) {
-                if (n_b[hf] == 0 || (int32_t)bl[hf][n_b[hf] - 1] + 1 != i) {
+            if (run[hf] && im >= minsc[hf]) {                   // (the last listed row lives in registers: see sw_core_wave4)
+                if (n_b[hf] == 0 || last_i[hf] + 1 != i) {
                     if (n_b[hf] >= W.cap_b) { err |= ERR_SCRATCH; stop[hf] = true; }
-                    else { if (sl == 0) bl[hf][n_b[hf]] = (uint64_t)im << 32 | (uint32_t)i; ++n_b[hf]; }
-                } else if ((int)(bl[hf][n_b[hf] - 1] >> 32) < im) { if (sl == 0) bl[hf][n_b[hf] - 1] = (uint64_t)im << 32 | (uint32_t)i; }
+                    else { if (sl == 0) bl[hf][n_b[hf]] = (uint64_t)im << 32 | (uint32_t)i; ++n_b[hf]; last_i[hf] = i; last_sc[hf] = im; }
+                } else if (last_sc[hf] < im) { if (sl == 0) bl[hf][n_b[hf] - 1] = (uint64_t)im << 32 | (uint32_t)i; last_i[hf] = i; last_sc[hf] = im; }
             }
         }
-        __syncthreads();
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int im = pk_half(imax, hf);

@@ -7,6 +7,7 @@
 #include <string.h>
 #include <vector>
 #include "../../gatk-bwamem-jni_amd/csrc/k_extend.hip"
+#include "../../gatk-bwamem-jni_amd/csrc/k_pe.hip"
 #include "../../gatk-bwamem-jni_amd/csrc/chain_flt.h"
 #include "../../gatk-bwamem-jni_amd/csrc/post_common.h"
 
@@ -196,4 +197,42 @@ extern "C" int unit_matesw_list(const MemOpt* opt, void* regs, int n0, const voi
     hipMemcpy(regs, d, (size_t)(n0 + n_add) * sizeof(AlnReg), hipMemcpyDeviceToHost);
     hipFree(d); hipFree(da); hipFree(k); hipFree(ds);
     return rc;
+}
+
+
+// ksw_align2 as mate rescue and seed re-scoring run it (k_pe.hip: launch_sw_jobs): n jobs, job i = query i (codes 0..4, qoff[i] ..
+// qoff[i+1]) against tlen[i] reference bases from toff[i] of a throw-away packed "reference"; xtra as mem_matesw builds it.
+// out: 7 ints per job (score, te, qe, score2, te2, tb, qb)
+extern "C" int unit_sw_jobs(const MemOpt* opt, int n, const uint8_t* queries, const int64_t* qoff, const uint8_t* target, int64_t l_target,
+                            const int64_t* toff, const int32_t* tlen, const int32_t* xtra, int32_t* out)
+{
+    std::vector<uint8_t> pac((size_t)l_target / 4 + 2, 0);
+    for (int64_t i = 0; i < l_target; ++i) pac[i >> 2] |= (uint8_t)((target[i] & 3) << ((~i & 3) << 1));
+    std::vector<SwJob> jobs((size_t)n);
+    int max_q = 0, max_t = 0;
+    for (int i = 0; i < n; ++i) {
+        SwJob& j = jobs[i];
+        j.rb = toff[i]; j.read = i; j.tag = i; j.l_ms = (int)(qoff[i + 1] - qoff[i]); j.is_rev = 0; j.tlen = tlen[i]; j.xtra = xtra[i]; j.q_off = 0; j.pad_ = 0;
+        max_q = j.l_ms > max_q ? j.l_ms : max_q; max_t = tlen[i] > max_t ? tlen[i] : max_t;
+    }
+    uint8_t *d_pac, *d_seq; int64_t* d_off; int32_t *d_err, *d_cnt; SwJob* d_jobs; KswR* d_res;
+    hipMalloc((void**)&d_pac, pac.size()); hipMalloc((void**)&d_seq, (size_t)qoff[n] + 64); hipMalloc((void**)&d_off, ((size_t)n + 1) * 8);
+    hipMalloc((void**)&d_err, 64); hipMalloc((void**)&d_cnt, 64); hipMalloc((void**)&d_jobs, (size_t)n * sizeof(SwJob) + 64); hipMalloc((void**)&d_res, pe_rescue_bytes(1, n) + 64);
+    hipMemcpy(d_pac, pac.data(), pac.size(), hipMemcpyHostToDevice);
+    hipMemcpy(d_seq, queries, (size_t)qoff[n], hipMemcpyHostToDevice);
+    hipMemcpy(d_off, qoff, ((size_t)n + 1) * 8, hipMemcpyHostToDevice);
+    hipMemset(d_err, 0, 64);
+    hipMemcpy(d_cnt, &n, 4, hipMemcpyHostToDevice);
+    hipMemcpy(d_jobs, jobs.data(), (size_t)n * sizeof(SwJob), hipMemcpyHostToDevice);
+    DevIndex ix; memset(&ix, 0, sizeof ix);
+    ix.pac = d_pac; ix.l_pac = l_target;
+    TileView tv; memset(&tv, 0, sizeof tv);
+    tv.n_reads = n; tv.max_len = max_q; tv.seq = d_seq; tv.seq_off = d_off; tv.err = d_err;
+    launch_sw_jobs(0, ix, *opt, tv, d_jobs, d_cnt, n, d_res, (max_t + max_q) / 2 + 16 /* as pipeline.cpp sizes it: (span + 2 L) / 2 + 16 */, max_q);
+    int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+    int32_t e = 0;
+    hipMemcpy(&e, d_err, 4, hipMemcpyDeviceToHost);
+    hipMemcpy(out, d_res, (size_t)n * sizeof(KswR), hipMemcpyDeviceToHost);
+    hipFree(d_pac); hipFree(d_seq); hipFree(d_off); hipFree(d_err); hipFree(d_cnt); hipFree(d_jobs); hipFree(d_res);
+    return rc ? rc : e;
 }

@@ -315,3 +315,63 @@ def test_units_emu_matesw_list():
 @pytest.mark.gpu
 def test_units_gpu_matesw_list():
     _check_matesw_list(_load("hip"), 120, 2500, 150)
+
+
+class _KswR(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("score", "te", "qe", "score2", "te2", "tb", "qb")]
+
+
+def _check_sw_jobs(units, oracle, n_jobs, seed):
+    """ksw_align2 as mate rescue (byte mode: two alignments per lane in packed halves for up to 160-base mates, one per 16-lane group
+    beyond) and seed re-scoring (16-bit mode) run it, job lists through launch_sw_jobs, against the oracle's o_ksw_align2: score,
+    end points, second best, and the start points of the reverse pass"""
+    oalign = oracle.dll.o_ksw_align2
+    oalign.restype = _KswR
+    oalign.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p] + [ctypes.c_int] * 5
+    units.unit_sw_jobs.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 4
+    rng = np.random.default_rng(seed)
+    opts = oracle.default_options()
+    ob = ctypes.create_string_buffer(bytes(opts), 168)
+    mat = bytes(opts[140:165])
+    target = rng.integers(0, 4, size=60000, dtype=np.uint8)
+    target[20000:20900] = np.tile(rng.integers(0, 4, size=45, dtype=np.uint8), 20)         # a tandem stretch: second-best hits, ties
+    qs, qoff, toff, tlen, xtra = [], [0], [], [], []
+    for it in range(n_jobs):
+        l = int(rng.choice([150, 150, 150, 100, 76, 30, 200, 249, 250, 256]))              # (beyond 256 bases the lane-scalar form runs: not a job kernel)
+        tl = int(rng.integers(max(30, l // 2), 900))
+        t0 = int(rng.integers(0, len(target) - tl))
+        if it % 5 == 0:
+            t0 = int(rng.integers(19900, 20500))
+        kind = it % 4
+        if kind == 3:                                                                   # unrelated query
+            q = rng.integers(0, 4, size=l, dtype=np.uint8)
+        else:                                                                           # a mutated stretch of the window (sometimes hanging over its end)
+            s = int(rng.integers(0, max(1, tl - l // 2)))
+            q = np.resize(target[t0 + s: t0 + s + l], l).copy()
+            mut = rng.random(l) < rng.choice([0.0, 0.02, 0.1])
+            q[mut] = rng.integers(0, 5, size=int(mut.sum()), dtype=np.uint8)
+            if rng.random() < 0.3 and l > 20:
+                cut = int(rng.integers(5, l - 5)); k = int(rng.integers(1, 6))
+                q = np.concatenate([q[:cut], q[cut + k:], rng.integers(0, 4, size=k, dtype=np.uint8)])
+        x = 0x40000 | 0x80000 | (0x10000 if l * 1 < 250 else 0) | 19                    # KSW_XSUBO | KSW_XSTART | (KSW_XBYTE) | min_seed_len * a
+        if it % 7 == 6:
+            x &= ~0x80000                                                               # seed re-scoring asks for the first pass only
+        qs.append(q); qoff.append(qoff[-1] + l); toff.append(t0); tlen.append(tl); xtra.append(x)
+    qcat = np.concatenate(qs).astype(np.uint8)
+    qoff, toff, tlen, xtra = (np.asarray(v, dtype=t) for v, t in ((qoff, np.int64), (toff, np.int64), (tlen, np.int32), (xtra, np.int32)))
+    out = np.zeros((n_jobs, 7), dtype=np.int32)
+    rc = units.unit_sw_jobs(ob, n_jobs, qcat.ctypes.data, qoff.ctypes.data, target.ctypes.data, len(target), toff.ctypes.data, tlen.ctypes.data, xtra.ctypes.data, out.ctypes.data)
+    assert rc == 0, rc
+    for i in range(n_jobs):
+        w = oalign(len(qs[i]), qs[i].tobytes(), int(tlen[i]), target[toff[i]: toff[i] + tlen[i]].tobytes(), 5, mat, 6, 1, 6, 1, int(xtra[i]))
+        want = [w.score, w.te, w.qe, w.score2, w.te2, w.tb, w.qb]
+        assert out[i].tolist() == want, (i, len(qs[i]), int(tlen[i]), hex(int(xtra[i])), out[i].tolist(), want)
+
+
+def test_units_emu_sw_jobs(oracle):
+    _check_sw_jobs(_load("emu"), oracle, 41, 7)
+
+
+@pytest.mark.gpu
+def test_units_gpu_sw_jobs(oracle):
+    _check_sw_jobs(_load("hip"), oracle, 3001, 8)
