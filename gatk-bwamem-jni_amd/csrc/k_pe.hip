@@ -445,25 +445,26 @@ __global__ void __launch_bounds__(64) k_pe_rescue_sw(DevIndex ix, MemOpt opt, Ti
     if (err) atomicOr(tv.err, err);
 }
 
-// the same for byte-mode jobs of up to NSEG segments, eight per wavefront (two per 16-lane group, one per half of every register:
-// sw_common.h: sw_core_wave8_u8); leaves every other job alone
-template <int NSEG>
-__global__ void __launch_bounds__(64) k_pe_rescue_sw8(DevIndex ix, MemOpt opt, TileView tv, const RescueJob* jobs, const int32_t* counter, int cap, KswR* results, int cap_b)
+// the same with two alignments per lane (sw_common.h: sw_core_packed): byte-mode jobs (U8) of LO < segments <= NSEG eight per
+// wavefront, 16-bit jobs sixteen; leaves every other job alone
+template <int LO, int NSEG, bool U8>
+__global__ void __launch_bounds__(64) k_pe_rescue_sw2(DevIndex ix, MemOpt opt, TileView tv, const RescueJob* jobs, const int32_t* counter, int cap, KswR* results, int cap_b)
 {
     HIP_DYNAMIC_SHARED(uint64_t, blists)
+    constexpr int GW = U8 ? 16 : 8, PER = 2 * (64 / GW);
     const int lane = threadIdx.x;
     if (tv.err[0] & ERR_RESCUE_CAP) return;
     const int n = *counter < cap ? *counter : cap;
-    if ((int)blockIdx.x * 8 >= n) return;
+    if ((int)blockIdx.x * PER >= n) return;
     SwPair P;
     int job[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        job[h] = blockIdx.x * 8 + (lane >> 4) * 2 + h;
+        job[h] = blockIdx.x * PER + (lane / GW) * 2 + h;
         RescueJob jb; jb.rb = 0; jb.read = 0; jb.tag = 0; jb.l_ms = 0; jb.is_rev = 0; jb.tlen = 0; jb.xtra = 0; jb.q_off = 0; jb.pad_ = 0;
         if (job[h] < n) jb = jobs[job[h]];
-        const int slen = (jb.l_ms + 15) / 16;
-        P.on[h] = job[h] < n && (jb.xtra & KSW_XBYTE) != 0 && slen > 0 && slen <= NSEG;
+        const int slen = (jb.l_ms + GW - 1) / GW;
+        P.on[h] = job[h] < n && ((jb.xtra & KSW_XBYTE) != 0) == U8 && slen > LO && slen <= NSEG;
         P.I[h].ms = tv.seq + tv.seq_off[jb.read] + jb.q_off; P.I[h].l_ms = jb.l_ms; P.I[h].is_rev = jb.is_rev; P.I[h].qrev = 0; P.I[h].t0 = jb.rb; P.I[h].trev = 0;
         P.qlen[h] = jb.l_ms; P.tlen[h] = jb.tlen; P.xtra[h] = jb.xtra;
     }
@@ -471,9 +472,9 @@ __global__ void __launch_bounds__(64) k_pe_rescue_sw8(DevIndex ix, MemOpt opt, T
     SwLds L; L.b = blists; L.cap_b = cap_b;
     int err = 0;
     KswR R[2];
-    sw_align2_wave8_u8<NSEG>(ix, opt, P, L, lane, err, R);
+    sw_align2_packed<NSEG, U8>(ix, opt, P, L, lane, err, R);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) if (P.on[h] && (lane & 15) == 0) results[job[h]] = R[h];
+    for (int h = 0; h < 2; ++h) if (P.on[h] && lane % GW == 0) results[job[h]] = R[h];
     if (err) atomicOr(tv.err, err);
 }
 
@@ -882,16 +883,22 @@ void launch_sw_jobs(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const
     // (seed re-scoring windows of long reads, 250 bp mates), 8 bases per segment, eight alignments per wave: up to 10, 11..16,
     // 17..25, 26..32 segments.
 #define SW_LAUNCH(LO, HI, GW) hipLaunchKernelGGL((k_pe_rescue_sw<LO, HI, GW>), dim3((cap + 64 / GW - 1) / (64 / GW)), dim3(64), (size_t)(64 / GW) * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b)
-    // byte mode up to 10 segments (150 bp mates): two alignments per lane in packed halves, eight per wave; BWAMEM_HIP_SW_PACKED=0: the
-    // one-value-per-register form (tests compare the two)
+    // two alignments per lane in packed halves (k_pe_rescue_sw2): byte mode up to 10 segments (150 bp mates), 16-bit mode up to 16 and 17..25
+    // segments (seed re-scoring windows, 250 bp mates).  BWAMEM_HIP_SW_PACKED=0: everything through the one-value-per-register form
     static const bool packed = []{ const char* e = getenv("BWAMEM_HIP_SW_PACKED"); return !(e && atoi(e) == 0); }();
-    if (packed) hipLaunchKernelGGL((k_pe_rescue_sw8<10>), dim3((cap + 7) / 8), dim3(64), (size_t)8 * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b);
-    else SW_LAUNCH(0, 10, 16);
+#define SW2_LAUNCH(LO, HI, U8) hipLaunchKernelGGL((k_pe_rescue_sw2<LO, HI, U8>), dim3((cap + (U8 ? 8 : 16) - 1) / (U8 ? 8 : 16)), dim3(64), (size_t)(U8 ? 8 : 16) * cap_b * 8, st, ix, opt, tv, (const SwJob*)jobs, cnt, cap, (KswR*)results, cap_b)
+    if (packed) SW2_LAUNCH(0, 10, true); else SW_LAUNCH(0, 10, 16);
     if (max_qlen > 160) SW_LAUNCH(10, 16, 16);
-    SW_LAUNCH(0, 10, 8);
-    if (max_qlen > 80) SW_LAUNCH(10, 16, 8);
-    if (max_qlen > 128) SW_LAUNCH(16, 25, 8);
+    if (packed) {
+        SW2_LAUNCH(0, 16, false);
+        if (max_qlen > 128) SW2_LAUNCH(16, 25, false);
+    } else {
+        SW_LAUNCH(0, 10, 8);
+        if (max_qlen > 80) SW_LAUNCH(10, 16, 8);
+        if (max_qlen > 128) SW_LAUNCH(16, 25, 8);
+    }
     if (max_qlen > 200) SW_LAUNCH(25, 32, 8);
+#undef SW2_LAUNCH
 #undef SW_LAUNCH
 }
 size_t pe_rescue_bytes(int what, int cap) { return what == 0 ? (size_t)cap * sizeof(RescueJob) : (size_t)cap * sizeof(KswR); }

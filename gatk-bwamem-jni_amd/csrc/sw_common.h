@@ -303,33 +303,38 @@ DEV KswR sw_align2_wave4(const DevIndex& ix, const MemOpt& opt, SwIn I, bool on,
 }
 
 
-// ------------------------------------------------------------------ byte mode, two alignments per lane
-// The byte-mode kernel above keeps one 8-bit value per 32-bit register.  Here every register carries two alignments, one per
-// 16-bit half (pk16.h): group g of 16 lanes runs alignments 2g (low halves) and 2g + 1 (high halves), eight per wavefront, and
-// one stream of packed instructions computes both -- unsigned saturation at 255 is a packed minimum, saturation at 0 the clamp
-// bit of the packed subtraction, and the scores of both alignments against their own target bases come out of one byte permute
-// (the lane keeps score + shift for the four target bases as the four bytes of a word per segment and alignment).  Everything
-// the two alignments do not share (target length, stop, the row-maxima list, the best row) is kept per half.  The lazy-F loop
-// runs whole passes until no half of the wave asks for more: a pass past an alignment's own fixed point changes nothing (at the
-// fixed point F is below H - o - e everywhere, which is what the pass would take the maximum with).
+// ------------------------------------------------------------------ two alignments per lane
+// The kernel above keeps one 8- or 16-bit value per 32-bit register.  Here every register carries two alignments, one per
+// 16-bit half (pk16.h): a group of GW lanes (16 in byte mode, 8 in 16-bit mode: upstream's vector width) runs alignments 2g (low
+// halves) and 2g + 1 (high halves) -- eight or sixteen per wavefront -- and one stream of packed instructions computes both.
+// Byte mode: unsigned saturation at 255 is a packed minimum, saturation at 0 the clamp bit of the packed subtraction.  16-bit
+// mode: the signed saturation of H + score cannot trigger for the queries these kernels take (at most 256 bases x the largest
+// byte score), so it is a plain packed add.  Either way the scores of both alignments against their own target bases come out of
+// one byte permute (the lane keeps a biased score for the four target bases as the four bytes of a word per segment and
+// alignment).  Everything the two alignments do not share (target length, stop, the row-maxima list, the best row) is kept
+// per half; segments beyond an alignment's own are masked, and F passes them unchanged.  The lazy-F loop runs whole passes until
+// no half of the wave asks for more: a pass past an alignment's own fixed point changes nothing (at the fixed point F is below
+// H - o - e everywhere, which is what the pass would take the maximum with).
 struct SwPair { SwIn I[2]; bool on[2]; int qlen[2], tlen[2], xtra[2]; };
 
-template <int NSEG>
-static __device__ __attribute__((noinline)) void sw_core_wave8_u8(const DevIndex& ix, const MemOpt& opt, const SwPair& P, const SwLds& W, int lane, int& err, KswR R[2])
+template <int NSEG, bool U8>
+static __device__ __attribute__((noinline)) void sw_core_packed(const DevIndex& ix, const MemOpt& opt, const SwPair& P, const SwLds& W, int lane, int& err, KswR R[2])
 {
-    const int g = lane >> 4, sl = lane & 15;
+    constexpr int GW = U8 ? 16 : 8;
+    const int g = lane / GW, sl = lane % GW;
     const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
     int lo = 127, hi = 0;
     for (int a = 0; a < 25; ++a) { if (opt.mat[a] < lo) lo = opt.mat[a]; if (opt.mat[a] > hi) hi = opt.mat[a]; }
     const int shift = (256 - (lo & 0xff)) & 0xff, qmax = hi;
-    const uint32_t SHIFT = pk_both(shift), C255 = pk_both(255), OED = pk_both(o_del + e_del), ED = pk_both(e_del), OEI = pk_both(o_ins + e_ins), EI = pk_both(e_ins);
+    const int bias = U8 ? shift : 128;                           // what is added to a score to make it an unsigned byte
+    const uint32_t BIAS = pk_both(bias), C255 = pk_both(255), OED = pk_both(o_del + e_del), ED = pk_both(e_del), OEI = pk_both(o_ins + e_ins), EI = pk_both(e_ins);
     int slen[2], n_b[2] = { 0, 0 }, te[2] = { -1, -1 }, gmax[2] = { 0, 0 }, minsc[2], endsc[2], last_i[2] = { -2, -2 }, last_sc[2] = { 0, 0 };
     bool stop[2];
     uint64_t* bl[2];
     PacCache pc[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        slen[h] = P.on[h] ? (P.qlen[h] + 15) / 16 : 0;
+        slen[h] = P.on[h] ? (P.qlen[h] + GW - 1) / GW : 0;
         minsc[h] = (P.xtra[h] & KSW_XSUBO) ? P.xtra[h] & 0xffff : 0x10000;
         endsc[h] = (P.xtra[h] & KSW_XSTOP) ? P.xtra[h] & 0xffff : 0x10000;
         stop[h] = !P.on[h];
@@ -349,10 +354,10 @@ static __device__ __attribute__((noinline)) void sw_core_wave8_u8(const DevIndex
             const bool pad = !(P.on[h] && j < slen[h] && pos < P.qlen[h]);
             uint32_t sp; int sn;
             score_lane(ST, pad ? 4 : sw_q(P.I[h], pos), sp, sn);
-            // score + shift per target base as unsigned bytes; a pad position scores 0 against everything
+            // score + bias per target base as unsigned bytes; a pad position scores 0 against everything
             uint32_t w = 0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) w |= (uint32_t)(((pad ? 0 : (int)(int8_t)(sp >> (b << 3))) + shift) & 0xff) << (b << 3);
+            for (int b = 0; b < 4; ++b) w |= (uint32_t)(((pad ? 0 : (int)(int8_t)(sp >> (b << 3))) + bias) & 0xff) << (b << 3);
             sw[h] = w;
         }
         SA[j] = sw[0]; SB[j] = sw[1];
@@ -379,8 +384,9 @@ static __device__ __attribute__((noinline)) void sw_core_wave8_u8(const DevIndex
 #pragma unroll
         for (int j = 0; j < NSEG; ++j) {                    // (segments beyond an alignment's own are masked, not skipped: no branches in the row)
             const uint32_t sc = pk_bytes2(SA[j], SB[j], tb[0], tb[1]);
-            uint32_t hh = pk_minu(pk_add(h, sc), C255);
-            hh = pk_subs(hh, SHIFT);
+            uint32_t hh;
+            if (U8) { hh = pk_minu(pk_add(h, sc), C255); hh = pk_subs(hh, BIAS); }
+            else hh = pk_sub(pk_add(h, sc), BIAS);
             hh = pk_max(hh, E[j]);
             hh = pk_max(hh, f) & sm[j];
             mx = pk_max(mx, hh);
@@ -407,7 +413,7 @@ static __device__ __attribute__((noinline)) void sw_core_wave8_u8(const DevIndex
             if (__ballot((more & runm) != 0) == 0ull) break;
         }
         uint32_t imax = mx;
-        for (int o = 8; o > 0; o >>= 1) imax = pk_max(imax, (uint32_t)__shfl_xor((int)imax, o));
+        for (int o = GW / 2; o > 0; o >>= 1) imax = pk_max(imax, (uint32_t)__shfl_xor((int)imax, o));
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int im = pk_half(imax, hf);
@@ -426,7 +432,8 @@ static __device__ __attribute__((noinline)) void sw_core_wave8_u8(const DevIndex
                 const uint32_t hm = hf ? 0xffff0000u : 0xffffu;
 #pragma unroll
                 for (int j = 0; j < NSEG; ++j) Hmax[j] = (Hmax[j] & ~hm) | (H1[j] & hm);
-                if (gmax[hf] + shift >= 255 || gmax[hf] >= endsc[hf]) stop[hf] = true;
+                if (U8) { if (gmax[hf] + shift >= 255 || gmax[hf] >= endsc[hf]) stop[hf] = true; }
+                else if (gmax[hf] >= endsc[hf]) stop[hf] = true;
             }
         }
 #pragma unroll
@@ -436,7 +443,7 @@ static __device__ __attribute__((noinline)) void sw_core_wave8_u8(const DevIndex
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
         KswR& r = R[hf];
-        r.score = gmax[hf] + shift < 255 ? gmax[hf] : 255;
+        r.score = U8 ? (gmax[hf] + shift < 255 ? gmax[hf] : 255) : gmax[hf];
         r.te = te[hf];
         int best = -1, bq = 0x7fffffff;
 #pragma unroll
@@ -446,11 +453,11 @@ static __device__ __attribute__((noinline)) void sw_core_wave8_u8(const DevIndex
                 if (v > best || (v == best && pos < bq)) { best = v; bq = pos; }
             }
         }
-        for (int o = 8; o > 0; o >>= 1) {
+        for (int o = GW / 2; o > 0; o >>= 1) {
             const int ub = __shfl_xor(best, o), uq = __shfl_xor(bq, o);
             if (ub > best || (ub == best && uq < bq)) { best = ub; bq = uq; }
         }
-        if (P.on[hf] && r.score != 255) {
+        if (P.on[hf] && (!U8 || r.score != 255)) {
             r.qe = bq;
             if (n_b[hf] > 0) {
                 int i = (r.score + qmax - 1) / qmax;
@@ -465,13 +472,13 @@ static __device__ __attribute__((noinline)) void sw_core_wave8_u8(const DevIndex
     __syncthreads();
 }
 
-// ksw_align2 in byte mode for the eight alignments of a wavefront (two per group of 16 lanes); P per lane, uniform within a group
-template <int NSEG>
-DEV void sw_align2_wave8_u8(const DevIndex& ix, const MemOpt& opt, SwPair P, const SwLds& W, int lane, int& err, KswR R[2])
+// ksw_align2 for the sixteen (byte mode: eight) alignments of a wavefront, two per group of GW lanes; P per lane, uniform within a group
+template <int NSEG, bool U8>
+DEV void sw_align2_packed(const DevIndex& ix, const MemOpt& opt, SwPair P, const SwLds& W, int lane, int& err, KswR R[2])
 {
 #pragma unroll
     for (int h = 0; h < 2; ++h) { P.I[h].qrev = 0; P.I[h].trev = 0; }
-    sw_core_wave8_u8<NSEG>(ix, opt, P, W, lane, err, R);
+    sw_core_packed<NSEG, U8>(ix, opt, P, W, lane, err, R);
     SwPair Q = P;
     bool again[2];
 #pragma unroll
@@ -484,7 +491,7 @@ DEV void sw_align2_wave8_u8(const DevIndex& ix, const MemOpt& opt, SwPair P, con
     }
     if (__ballot(again[0] || again[1]) == 0ull) return;
     KswR RR[2];
-    sw_core_wave8_u8<NSEG>(ix, opt, Q, W, lane, err, RR);
+    sw_core_packed<NSEG, U8>(ix, opt, Q, W, lane, err, RR);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
         if (again[h] && R[h].score == RR[h].score) { R[h].tb = R[h].te - RR[h].te; R[h].qb = R[h].qe - RR[h].qe; }
