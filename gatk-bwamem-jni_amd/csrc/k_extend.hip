@@ -498,6 +498,202 @@ static __device__ ExtRes extend_wave_pk2(const DevIndex& ix, const MemOpt& opt, 
     return r;
 }
 
+// The packed form for queries of any length: the same halves-of-a-register arithmetic as extend_wave_pk2, with the H and E rows
+// in LDS instead of registers.  Columns are grouped in aligned pairs of 64-column chunks (pair p = columns 128 p .. 128 p + 127; lane
+// l owns 128 p + l in the low and 128 p + 64 + l in the high half of one packed word), and only the pairs the band touches are
+// live: the rows are rings of NP pairs (the LDS the general form's three int rows use holds them with room to spare).  Because
+// a lane keeps H(i, j - 1) for its *own* column j -- the shift by one column is a DPP move with carries between halves and
+// pairs, as in the register forms -- a row is one pass over the pairs: no intermediate M row, one barrier less than the general
+// form, half its arithmetic.  F's prefix maximum runs on column offsets relative to the row's first pair, so that its operands
+// stay small whatever the query length.  Usable when the scores fit 16 bits and the ring holds the band: extend_pkl_ok().
+static __device__ inline bool extend_pkl_ok(const MemOpt& opt, int ring_ints, int qlen, int w, int h0, int mx)
+{
+    if (ring_ints < 64 || ring_ints > (1 << 20)) return false;
+    const int np = ring_ints >> 6;                                  // pairs the ring holds (a power of two)
+    return opt.e_ins >= 0 && opt.e_del >= 0 && opt.o_ins >= 0 && opt.o_del >= 0 && mx > 0 && qlen < 65536
+        && (long long)(h0 > 0 ? h0 : 0) + (long long)qlen * mx + (long long)(np * 128 + 130) * opt.e_ins < 30000 && opt.o_ins + opt.e_ins < 30000 && opt.o_del + opt.e_del < 30000
+        && 2ll * w + 4 <= (long long)np * 128;        // the live columns (i - w .. i + w + 2) never meet a column 128 np further on in the ring
+}
+static __device__ ExtRes extend_wave_pkl(const DevIndex& ix, const MemOpt& opt, const ExtLds& L, int lane,
+                                         int qlen, int q0, int qstep, int tlen, int64_t t0, int tstep,
+                                         int w, int end_bonus, int zdrop, int h0, unsigned long long& n_cells)
+{
+    const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    int i, beg, end, max, max_i, max_j, max_ins, max_del, max_ie, gscore, max_off;
+    if (h0 < 0) h0 = 0;
+    uint32_t* const EH = (uint32_t*)L.eh_h;                        // [NP][64] packed H rows: H(i-1, j-1) for the lane's two columns
+    uint32_t* const EE = (uint32_t*)L.eh_e;                        // [NP][64] packed E rows
+    const int NPM = ((L.rm + 1) >> 6) - 1;                         // ring mask over pairs
+    const ScoreTab ST = score_tab(opt);
+    const int mx = score_max(opt);
+    {
+        max_ins = div_plus(qlen * mx + end_bonus - o_ins, e_ins, 1);
+        max_ins = max_ins > 1 ? max_ins : 1;
+        w = w < max_ins ? w : max_ins;
+        max_del = div_plus(qlen * mx + end_bonus - o_del, e_del, 1);
+        max_del = max_del > 1 ? max_del : 1;
+        w = w < max_del ? w : max_del;
+    }
+#define PKL_INIT_H(j) ((j) == 0 ? h0 : h0 > oe_ins && h0 - oe_ins - ((j) - 1) * e_ins > 0 ? h0 - oe_ins - ((j) - 1) * e_ins : 0)
+#define PKL_SLOT(j) (((((j) >> 7) & NPM) << 6) + ((j) & 63))
+    // one column's H (and E = 0) into its half of its slot; called by all lanes, done by the owning one
+#define PKL_SET_COL(j, hv, with_e) do { if (lane == ((j) & 63)) { const uint32_t hm_ = ((j) >> 6 & 1) ? 0xffff0000u : 0xffffu; const int s_ = PKL_SLOT(j); \
+        EH[s_] = (EH[s_] & ~hm_) | (pk_both(hv) & hm_); if (with_e) EE[s_] = EE[s_] & ~hm_; } } while (0)
+    // first row: columns 0 .. min(qlen, w + 1); every row below adds the column the band is about to reach
+    for (int pp = 0; pp <= ((qlen < w + 1 ? qlen : w + 1) >> 7); ++pp) {
+        const int jl = (pp << 7) + lane, jh = jl + WAVE;
+        EH[((pp & NPM) << 6) + lane] = pk_pair(jl <= qlen && jl <= w + 1 ? PKL_INIT_H(jl) : 0, jh <= qlen && jh <= w + 1 ? PKL_INIT_H(jh) : 0);
+        EE[((pp & NPM) << 6) + lane] = 0;
+    }
+    const uint32_t OEIB = pk_both(oe_ins + 128), OEDB = pk_both(oe_del + 128), ED = pk_both(e_del), ONE = pk_both(1), BIAS = pk_both(128);
+    const uint32_t JE0 = pk_pair(lane * e_ins, (lane + WAVE) * e_ins), JM0 = pk_pair((lane - 1) * e_ins, (lane + WAVE - 1) * e_ins);
+    max = h0; max_i = max_j = -1; max_ie = -1; gscore = -1; max_off = 0;
+    beg = 0; end = qlen;
+    int tch = 4;
+    __syncthreads();
+    for (i = 0; i < tlen; ++i) {
+        if ((i & 63) == 0) { int ii = i + lane; tch = ii < tlen ? ref_base2(ix, t0 + (int64_t)tstep * ii) : 4; }
+        const int tb = wave_readlane(tch, i & 63);
+        // the column the band reaches in this row enters the ring (its slot may still hold a column 128 NP to the left)
+        if (i + w + 1 <= qlen) { const int jn = i + w + 1; PKL_SET_COL(jn, PKL_INIT_H(jn), true); }
+        int m, mj, h1, h1i;
+        if (beg < i - w) beg = i - w;
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        if (beg == 0) { h1i = h0 - (o_del + e_del * (i + 1)); if (h1i < 0) h1i = 0; }
+        else h1i = 0;
+        h1 = h1i;
+        // score of a query base against this row's target base, biased by 128: bytes 0..3 = bases A..T, an ambiguous base apart
+        const uint32_t msw = (uint32_t)(uint8_t)(score_at(ST.p[0], ST.n[0], tb) + 128) | (uint32_t)(uint8_t)(score_at(ST.p[1], ST.n[1], tb) + 128) << 8
+                           | (uint32_t)(uint8_t)(score_at(ST.p[2], ST.n[2], tb) + 128) << 16 | (uint32_t)(uint8_t)(score_at(ST.p[3], ST.n[3], tb) + 128) << 24;
+        const uint32_t msn = (uint32_t)(uint8_t)(score_at(ST.p[4], ST.n[4], tb) + 128);
+        // (every word of the rows is read and written by one lane only -- the owner of its two columns -- so the row needs no barrier)
+        int kmax = -1;
+        if (end > beg) {
+            const int pb = beg >> 7, pe = (end - 1) >> 7;
+            uint32_t carryU = 0, fillh = 0xffffu;                // F's running maximum and H of the column left of the pair, from the pairs before
+            for (int pr = pb; pr <= pe; ++pr) {
+                const int jlo = (pr << 7) + lane, jhi = jlo + WAVE, slot = ((pr & NPM) << 6) + lane;
+                const bool a_lo = jlo >= beg && jlo < end, a_hi = jhi >= beg && jhi < end;
+                const uint32_t am = (a_lo ? 0xffffu : 0u) | (a_hi ? 0xffff0000u : 0u);
+                const int qlo = jlo < qlen ? L.query[q0 + qstep * jlo] : 4, qhi = jhi < qlen ? L.query[q0 + qstep * jhi] : 4;
+                const uint32_t sc = (qlo < 4 ? msw >> (qlo << 3) & 0xffu : msn) | (qhi < 4 ? msw >> (qhi << 3) & 0xffu : msn) << 16;
+                const uint32_t Mp = EH[slot], e = EE[slot];
+                const uint32_t Mb = pk_add(Mp, sc) & am & ~pk_sra15(pk_sub(Mp, ONE));
+                const uint32_t M = pk_sub(Mb, BIAS);
+                const uint32_t tt = pk_max(pk_sub(Mb, OEIB), 0u);
+                const uint32_t joff = pk_both(((pr - pb) << 7) * e_ins);
+                uint32_t P = pk_add(tt, pk_add(JE0, joff));
+                P = pk_max(P, PK_DPP_ZERO(P, DPP_ROW_SHR(1), 0xf));
+                P = pk_max(P, PK_DPP_ZERO(P, DPP_ROW_SHR(2), 0xf));
+                P = pk_max(P, PK_DPP_ZERO(P, DPP_ROW_SHR(4), 0xf));
+                P = pk_max(P, PK_DPP_ZERO(P, DPP_ROW_SHR(8), 0xf));
+                P = pk_max(P, PK_DPP_ZERO(P, DPP_ROW_BCAST15, 0xa));
+                P = pk_max(P, PK_DPP_ZERO(P, DPP_ROW_BCAST31, 0xc));
+                uint32_t Pex = PK_DPP_ZERO(P, DPP_WAVE_SHR1, 0xf);
+                const uint32_t plast = (uint32_t)wave_readlane((int)P, 63);
+                Pex = pk_max(Pex, pk_max(carryU, plast << 16));       // earlier pairs feed both halves, the first chunk feeds the second
+                carryU = pk_max(carryU, pk_both((int)(plast >> 16)));
+                carryU = pk_max(carryU, pk_both((int)(plast & 0xffffu)));
+                // F = (maximum of U before the column) - (offset of the column before it); nothing precedes the row's very first offset
+                uint32_t jm1 = pk_add(JM0, joff);
+                if (pr == pb && lane == 0) jm1 &= 0xffff0000u;
+                const uint32_t f = pk_sub(Pex, jm1);
+                uint32_t h = pk_max(pk_max(M, e), f);
+                h = (h & am) | ~am;                                    // -1 outside the live columns
+                const int klo = (int)((uint32_t)(int)(int16_t)(h & 0xffffu) << 16) | jlo, khi = (int)(h & 0xffff0000u) | jhi;
+                const int kk = klo > khi ? klo : khi;
+                kmax = kmax > kk ? kmax : kk;
+                const uint32_t t2 = pk_max(pk_sub(Mb, OEDB), 0u);
+                const uint32_t en = pk_max(pk_sub(e, ED), t2);
+                if (pr == pe) { const int v = wave_readlane((int)h, (end - 1) & 63); h1 = ((end - 1) >> 6 & 1) ? v >> 16 : (int)(int16_t)(v & 0xffff); }
+                const uint32_t h63 = (uint32_t)wave_readlane((int)h, 63);
+                const uint32_t fill = h63 << 16 | fillh;              // lane 0: column 63 of this pair left of column 64, the pair before left of column 0
+                const uint32_t hsh = (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)h, DPP_WAVE_SHR1, 0xf, 0xf, false);
+                fillh = h63 >> 16;
+                const uint32_t dead = pk_sra15(hsh);                   // halves whose left neighbour was not live keep their value
+                EH[slot] = (Mp & dead) | (hsh & ~dead);
+                EE[slot] = (en & am) | (e & ~am);
+            }
+            n_cells += (unsigned long long)(end - beg);
+        }
+        // the row's single cells: eh[beg].h = first-column value, eh[end].h = H(i, end - 1) (first-column value when the window is empty), eh[end].e = 0
+        if (end > beg) { PKL_SET_COL(beg, h1i, false); }
+        { const int hv = end > beg ? h1 : h1i; PKL_SET_COL(end, hv, true); }
+        const int best = wave_readlane(dpp_prefix_max(kmax, -1), 63);
+        m = best < 0 ? 0 : best >> 16;
+        mj = best < 0 ? -1 : best & 0xffff;
+        {
+            const int jafter = end > beg ? end : beg;
+            if (jafter == qlen) {
+                max_ie = gscore > h1 ? max_ie : i;
+                gscore = gscore > h1 ? gscore : h1;
+            }
+        }
+        if (m == 0) break;
+        if (m > max) {
+            max = m; max_i = i; max_j = mj;
+            int d = mj - i; d = d < 0 ? -d : d;
+            max_off = max_off > d ? max_off : d;
+        } else if (zdrop > 0) {
+            if (i - max_i > mj - max_j) {
+                if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
+            } else {
+                if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
+            }
+        }
+        {   // shrink the window to the non-zero span of the row just written
+            int nb = end, jl = -2;
+            for (int pr = beg >> 7; pr <= (end - 1) >> 7 && nb == end && end > beg; ++pr) {
+                const int jlo = (pr << 7) + lane, jhi = jlo + WAVE, slot = ((pr & NPM) << 6) + lane;
+                const uint32_t nz = EH[slot] | EE[slot];
+                const unsigned long long fl = wave_ballot((nz & 0xffffu) != 0 && jlo >= beg && jlo < end), fh = wave_ballot((nz >> 16) != 0 && jhi >= beg && jhi < end);
+                if (fl) nb = (pr << 7) + __ffsll((long long)fl) - 1;
+                else if (fh) nb = (pr << 7) + WAVE + __ffsll((long long)fh) - 1;
+            }
+            beg = nb;
+            for (int pr = end >> 7; pr >= beg >> 7 && jl == -2; --pr) {
+                const int jlo = (pr << 7) + lane, jhi = jlo + WAVE, slot = ((pr & NPM) << 6) + lane;
+                const uint32_t nz = EH[slot] | EE[slot];
+                const unsigned long long gl = wave_ballot((nz & 0xffffu) != 0 && jlo >= beg && jlo <= end), gh = wave_ballot((nz >> 16) != 0 && jhi >= beg && jhi <= end);
+                if (gh) jl = (pr << 7) + WAVE + 63 - __clzll((long long)gh);
+                else if (gl) jl = (pr << 7) + 63 - __clzll((long long)gl);
+            }
+            if (jl == -2) jl = beg - 1;
+            end = jl + 2 < qlen ? jl + 2 : qlen;
+        }
+        if (gscore > 0 && m + mx * (qlen - 1 - mj) <= max) {   // see ext_bound(): the remaining rows cannot change the result
+            int B = 0;
+            const int lim = qlen < i + w + 3 ? qlen : i + w + 3;        // columns the ring holds (the next row's entering column included)
+            if (i + w + 2 <= qlen) { const int jn = i + w + 2; PKL_SET_COL(jn, PKL_INIT_H(jn), true); }
+            for (int pr = beg >> 7; pr <= (lim - 1) >> 7 && lim > beg; ++pr) {
+                const int slot = ((pr & NPM) << 6) + lane;
+                const uint32_t hw = EH[slot], ew = EE[slot];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int j = (pr << 7) + t * WAVE + lane;
+                    const int hh = t ? (int)hw >> 16 : (int)(int16_t)(hw & 0xffffu), ee = t ? (int)ew >> 16 : (int)(int16_t)(ew & 0xffffu);
+                    const int term = j >= beg && j < lim ? ext_bound_term(hh, ee, mx, qlen - 1 - j) : 0;
+                    const int bc = wave_readlane(dpp_prefix_max(term, 0), 63);
+                    B = B > bc ? B : bc;
+                }
+            }
+            // columns beyond hold the untouched first row, whose terms fall with j: the first of them is the largest
+            if (lim < qlen) { const int t0_ = ext_bound_term(PKL_INIT_H(lim), 0, mx, qlen - 1 - lim); B = B > t0_ ? B : t0_; }
+            if (beg == 0) { const int hb = h0 - (o_del + e_del * (i + 2)); if (hb > 0 && hb + mx * qlen > B) B = hb + mx * qlen; }
+            if (B <= max && B < gscore) break;
+        }
+    }
+#undef PKL_INIT_H
+#undef PKL_SLOT
+#undef PKL_SET_COL
+    __syncthreads();
+    ExtRes r;
+    r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+    return r;
+}
+
 // The diagonal certificate: many extensions of well-placed reads run along the seed's diagonal with at most one mismatch,
 // and then the banded DP is decided before it starts.  Let s_j = mat[t_j][q_j] be the scores on the diagonal, a = max(mat),
 // D = sum_j (a - s_j) over the whole query (the "deficit") and g = min(o_del + e_del, o_ins + e_ins).  A path from the origin
@@ -565,6 +761,8 @@ static __device__ ExtRes extend_any(const DevIndex& ix, const MemOpt& opt, const
     if (pk2 && extend_pk2_ok(opt, qlen, h0, score_max(opt))) return extend_wave_pk2(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
     if (qlen + 1 <= 2 * WAVE) return extend_wave_reg<2>(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
     if (qlen + 1 <= 3 * WAVE) return extend_wave_reg<3>(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
+    if (pk2 && L.rm != 0x7fffffff && extend_pkl_ok(opt, L.rm + 1, qlen, w, h0, score_max(opt)))
+        return extend_wave_pkl(ix, opt, L, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
     return extend_wave(ix, opt, L, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
 }
 

@@ -31,7 +31,10 @@ __global__ void __launch_bounds__(64) k_unit_extend(DevIndex ix, MemOpt opt, con
     unsigned long long n_cells = 0;
     // 0: the 32-bit register forms; 1: the general LDS form; 2: the production entry (diagonal certificate first, packed 16-bit form
     // for two-chunk queries); 3: the production entry without the certificate (so that the packed form sees every case it accepts)
+    // 4: the packed form with its rows in LDS (what queries beyond 191 bases take) on whatever query it accepts, the general form otherwise
     ExtRes r = force_lds == 1 ? extend_wave(ix, opt, L, lane, qlen, 0, 1, tlen, 0, 1, w, end_bonus, zdrop, h0, n_cells)
+             : force_lds == 4 ? (extend_pkl_ok(opt, L.rm + 1, qlen, w, h0, score_max(opt)) ? extend_wave_pkl(ix, opt, L, lane, qlen, 0, 1, tlen, 0, 1, w, end_bonus, zdrop, h0, n_cells)
+                                                                                             : extend_wave(ix, opt, L, lane, qlen, 0, 1, tlen, 0, 1, w, end_bonus, zdrop, h0, n_cells))
                          : extend_any(ix, opt, L, lane, qlen, 0, 1, tlen, 0, 1, w, end_bonus, zdrop, h0, n_cells, force_lds == 2, force_lds >= 2);
     if (lane == 0) { out[0] = r.score; out[1] = r.qle; out[2] = r.tle; out[3] = r.gtle; out[4] = r.gscore; out[5] = r.max_off; }
 }

@@ -91,7 +91,7 @@ def _check_extend(units, oracle, n_cases, max_q):
                   ctypes.byref(want, 0), ctypes.byref(want, 4), ctypes.byref(want, 8), ctypes.byref(want, 12), ctypes.byref(want, 16))
         got = (ctypes.c_int * 6)()
         ob = ctypes.create_string_buffer(bytes(opts), 168)
-        for force_lds in (0, 1, 2, 3):    # the 32-bit register forms (when the query fits), the general LDS form, the production entry (diagonal certificate first,
+        for force_lds in (0, 1, 2, 3, 4): # (4: the packed form with its rows in LDS, the one long reads take) the 32-bit register forms (when the query fits), the general LDS form, the production entry (diagonal certificate first,
                                           # packed 16-bit form for 64..126-base queries), and the same without the certificate
             assert units.unit_extend(q.tobytes(), qlen, t.tobytes(), tlen, ob, w, end_bonus, zdrop, h0, got, force_lds) == 0
             assert list(got) == [ws, want[0], want[1], want[2], want[3], want[4]], (it, force_lds, qlen, tlen, kw, w, zdrop, h0)
@@ -127,7 +127,7 @@ def _check_extend_16bit_boundary(units, oracle, qlens=(126, 100, 65)):
                           ctypes.byref(want, 0), ctypes.byref(want, 4), ctypes.byref(want, 8), ctypes.byref(want, 12), ctypes.byref(want, 16))
                 ob = ctypes.create_string_buffer(bytes(opts), 168)
                 got = (ctypes.c_int * 6)()
-                for mode in (0, 3):
+                for mode in (0, 3, 4):
                     assert units.unit_extend(q.tobytes(), qlen, t.tobytes(), tlen, ob, 100, 5, 0, h0, got, mode) == 0
                     assert list(got) == [ws, want[0], want[1], want[2], want[3], want[4]], (qlen, e_ins, h0, mode, list(got), ws, list(want))
                 assert ws > 5000                                       # (the scores really are beyond what a byte or a careless 16-bit sum holds)
@@ -375,3 +375,44 @@ def test_units_emu_sw_jobs(oracle):
 @pytest.mark.gpu
 def test_units_gpu_sw_jobs(oracle):
     _check_sw_jobs(_load("hip"), oracle, 3001, 8)
+
+
+def _check_extend_long(units, oracle, n_cases, max_q, seed=19):
+    """queries beyond the register forms (the band slides along rows kept in LDS rings): the general form and the packed form with
+    its lane-private pair rings, on long extensions with substitutions and indels, bands of 100 and 200"""
+    oext = oracle.dll.o_ksw_extend2
+    oext.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p] * 5
+    rng = np.random.default_rng(seed)
+    opts = oracle.default_options()
+    ob = ctypes.create_string_buffer(bytes(opts), 168)
+    for it in range(n_cases):
+        qlen = int(rng.integers(200, max_q)); tlen = qlen + int(rng.integers(-60, 200))
+        t = rng.integers(0, 4, size=max(tlen, 10), dtype=np.uint8); tlen = len(t)
+        rate = float(rng.choice([0.01, 0.05, 0.14]))
+        q = []
+        i = 0
+        while len(q) < qlen and i < tlen:                           # ONT-like: substitutions, single-base insertions and deletions
+            r = rng.random()
+            if r < rate / 4: i += 1; continue
+            if r < rate / 2: q.append(int(rng.integers(0, 4))); continue
+            q.append(int((t[i] + (1 + rng.integers(0, 3)) * (rng.random() < rate)) % 4)); i += 1
+        q = np.array(q + [int(x) for x in rng.integers(0, 4, size=qlen - len(q))], dtype=np.uint8)
+        if it % 4 == 3:
+            q[len(q) // 2:] = rng.integers(0, 4, size=len(q) - len(q) // 2, dtype=np.uint8)     # the second half unrelated: z-drop / early end
+        w = int(rng.choice([100, 200])); zdrop = int(rng.choice([100, 100, 0])); h0 = int(rng.integers(19, 200))
+        want = (ctypes.c_int * 5)()
+        ws = oext(qlen, q.tobytes(), tlen, t.tobytes(), 5, bytes(opts[140:165]), 6, 1, 6, 1, w, 5, zdrop, h0,
+                  ctypes.byref(want, 0), ctypes.byref(want, 4), ctypes.byref(want, 8), ctypes.byref(want, 12), ctypes.byref(want, 16))
+        got = (ctypes.c_int * 6)()
+        for mode in (1, 2, 4):
+            assert units.unit_extend(q.tobytes(), qlen, t.tobytes(), tlen, ob, w, 5, zdrop, h0, got, mode) == 0
+            assert list(got) == [ws, want[0], want[1], want[2], want[3], want[4]], (it, mode, qlen, tlen, w, zdrop, h0, list(got), ws, list(want))
+
+
+def test_units_emu_extend_long(oracle):
+    _check_extend_long(_load("emu"), oracle, 6, 900)
+
+
+@pytest.mark.gpu
+def test_units_gpu_extend_long(oracle):
+    _check_extend_long(_load("hip"), oracle, 120, 6000)
