@@ -10,6 +10,24 @@
 
 #define DEV static __device__ inline
 
+// A pointer whose origin the compiler cannot see (chosen at run time between LDS and global memory, or read back from a struct
+// passed by reference to a function that is not inlined) makes every access a *flat* one: slower, and counted on both the
+// vector-memory and the LDS counter, so the next LDS read waits for every global store still in flight.  Where the code knows
+// the space it says so.  (Device pass only: the host pass of hipcc and the g++ build of tests/emu see plain pointers.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AS_GLOBAL(T, p) ((T __attribute__((address_space(1)))*)(p))
+#define AS_LDS(T, p) ((T __attribute__((address_space(3)))*)(p))
+#else
+#define AS_GLOBAL(T, p) ((T*)(p))
+#define AS_LDS(T, p) ((T*)(p))
+#endif
+// a load that does not trust the CU's vector cache: for words another lane of the workgroup has just stored (after a barrier)
+#if defined(__HIP_DEVICE_COMPILE__)
+DEV uint32_t load_fresh(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+DEV uint32_t load_fresh(const uint32_t* p) { return *p; }
+#endif
+
 // ---------------------------------------------------------------- rank queries (row a2)
 // counts of A,C,G,T among the first n (0..16) symbols of a 16-symbol word (MSB first)
 DEV void cnt_word(uint32_t x, int n, uint32_t& c1, uint32_t& c2, uint32_t& c3)
@@ -136,7 +154,7 @@ DEV uint64_t sa_lookup(const DevIndex& ix, uint64_t k, uint32_t& n_lf)
 }
 
 // ---------------------------------------------------------------- reference access (U8)
-DEV int pac_base(const uint8_t* pac, int64_t l) { return pac[l >> 2] >> ((~l & 3) << 1) & 3; }
+DEV int pac_base(const uint8_t* pac, int64_t l) { return *AS_GLOBAL(const uint8_t, pac + (l >> 2)) >> ((~l & 3) << 1) & 3; }   // (the packed reference is always in global memory)
 
 // base at position p of the doubled (forward + reverse-complement) coordinate system
 DEV int ref_base2(const DevIndex& ix, int64_t p)
@@ -146,16 +164,17 @@ DEV int ref_base2(const DevIndex& ix, int64_t p)
 
 // ref_base2 through a one-word cache: 16 reference bases per global load for loops that walk a stretch of the reference
 struct PacCache { int64_t w; uint32_t v; };
-DEV int ref_base2_c(const DevIndex& ix, PacCache& c, int64_t p)
+DEV int ref_base2_cp(const uint8_t* pac, int64_t l_pac, PacCache& c, int64_t p)
 {
-    const bool rev = p >= ix.l_pac;
-    const int64_t l = rev ? (ix.l_pac << 1) - 1 - p : p;
+    const bool rev = p >= l_pac;
+    const int64_t l = rev ? (l_pac << 1) - 1 - p : p;
     const int64_t w = l >> 4;
-    if (w != c.w) { c.w = w; c.v = ((const uint32_t*)ix.pac)[w]; }
+    if (w != c.w) { c.w = w; c.v = *AS_GLOBAL(const uint32_t, (const uint32_t*)pac + w); }
     const int k = (int)(l & 15);
     const int b = (int)(c.v >> (((k >> 2) << 3) + 6 - ((k & 3) << 1)) & 3u);
     return rev ? 3 - b : b;
 }
+DEV int ref_base2_c(const DevIndex& ix, PacCache& c, int64_t p) { return ref_base2_cp(ix.pac, ix.l_pac, c, p); }
 
 DEV int64_t bns_depos(const DevIndex& ix, int64_t pos, int& is_rev)
 {

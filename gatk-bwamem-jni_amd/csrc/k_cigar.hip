@@ -15,13 +15,22 @@
 
 #define NEG_SCAN (-2000000000)
 
+// BWAMEM_HIP_DEBUGK bit 0x2000: shader clocks of the wave form's phases, summed over wavefronts into DevCounters::dbg[5..7]
+// (DP rows, staging of traceback tiles, lane 0's walk); clk == 0: no clock is read
+struct GClk { unsigned long long* c; long long t; };
+DEV void gclk(GClk& K, int k) { if (K.c) { const long long t = clock64(); if (threadIdx.x == 0) atomicAdd(K.c + k, (unsigned long long)(t - K.t)); K.t = clock64(); } }
+
 struct GLds { int32_t* eh_h; int32_t* eh_e; int32_t* tmpM; int rm; };   // rm: ring mask of the rows (only columns i - w .. i + w + 1 are live: see ExtLds in k_extend.hip); ~0 for rows in global memory
 
 // backtrack through the direction bytes (lane 0); ops come out end-to-start and are reversed in place.  The run being
 // built stays in registers: the CIGAR pool is global memory, and a read-modify-write per step would put a global
 // round trip on every one of the ~tlen steps.
-static __device__ int traceback(const uint8_t* z, int n_col, int w, int tlen, int qlen, int lane, uint32_t* cigar, int cig_cap, int& err, uint8_t* tile)
+DEV void z_put(uint8_t* p, uint8_t v, bool z_lds) { if (z_lds) *AS_LDS(uint8_t, p) = v; else *AS_GLOBAL(uint8_t, p) = v; }
+DEV int z_get(const uint8_t* p, bool z_lds) { return z_lds ? *AS_LDS(const uint8_t, p) : *AS_GLOBAL(const uint8_t, p); }
+
+static __device__ int traceback(const uint8_t* z, bool z_lds, int n_col, int w, int tlen, int qlen, int lane, uint32_t* cigar, int cig_cap, int& err, uint8_t* tile, GClk& K)
 {
+    gclk(K, 5);
     int n = 0;
     int which = 0, i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
     int cur_op = -1;
@@ -32,7 +41,7 @@ static __device__ int traceback(const uint8_t* z, int n_col, int w, int tlen, in
     if (!tile) {                                                  // the matrix is in LDS: lane 0 walks it directly
         if (lane == 0)
             while (i >= 0 && k >= 0 && !ovf) {
-                which = z[i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+                which = z_get(z + ((int64_t)i * n_col + (k - (i > w ? i - w : 0))), z_lds) >> (which << 1) & 3;
                 if (which == 0) { TB_PUSH(0, 1); --i; --k; }
                 else if (which == 1) { TB_PUSH(2, 1); --i; }
                 else { TB_PUSH(1, 1); --k; }
@@ -46,39 +55,54 @@ static __device__ int traceback(const uint8_t* z, int n_col, int w, int tlen, in
             const int i0 = wave_bcast(i, 0), k0 = wave_bcast(k, 0);
             if (i0 < 0 || k0 < 0 || wave_bcast(ovf ? 1 : 0, 0)) break;
             __syncthreads();
-            for (int t = 0; t < 64; ++t) {
-                const int r = i0 - t, c = k0 - 63 + lane;
-                uint8_t bt = 0;
-                if (r >= 0 && c >= 0) {
+            // (every load unconditional -- cells outside the matrix read z[0] and are zeroed afterwards -- and sixteen rows per
+            // batch, so a batch is sixteen loads in flight, not sixteen round trips: with one conditional load per iteration
+            // this loop alone was 16 of the 23 ms of a 10 kb job)
+            for (int t0 = 0; t0 < 64; t0 += 16) {
+                uint8_t bt[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int r = i0 - (t0 + u), c = k0 - 63 + lane;
                     const int rb = r > w ? r - w : 0, re = r + w + 1 < qlen ? r + w + 1 : qlen;
-                    if (c >= rb && c < re) bt = z[(int64_t)r * n_col + (c - rb)];
+                    const bool in = r >= 0 && c >= rb && c < re;
+                    const uint8_t v = *AS_GLOBAL(const uint8_t, z + (in ? (int64_t)r * n_col + (c - rb) : 0));
+                    bt[u] = in ? v : (uint8_t)0;
                 }
-                tile[t * 64 + lane] = bt;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) *AS_LDS(uint8_t, tile + ((t0 + u) * 64 + lane)) = bt[u];
             }
             __syncthreads();
+            gclk(K, 6);
             if (lane == 0)
                 while (i >= 0 && k >= 0 && !ovf && i > i0 - 64 && k > k0 - 64) {
-                    which = tile[(i0 - i) * 64 + (k - (k0 - 63))] >> (which << 1) & 3;
+                    which = *AS_LDS(const uint8_t, tile + ((i0 - i) * 64 + (k - (k0 - 63)))) >> (which << 1) & 3;
                     if (which == 0) { TB_PUSH(0, 1); --i; --k; }
                     else if (which == 1) { TB_PUSH(2, 1); --i; }
                     else { TB_PUSH(1, 1); --k; }
                 }
+            gclk(K, 7);
         }
     }
     if (lane == 0) {
         if (!ovf && i >= 0) TB_PUSH(2, i + 1);
         if (!ovf && k >= 0) TB_PUSH(1, k + 1);
         if (!ovf) TB_PUSH(-1, 0);                                 // flush the last run
-        for (int a = 0; a < n >> 1; ++a) { uint32_t tmp = cigar[a]; cigar[a] = cigar[n - 1 - a]; cigar[n - 1 - a] = tmp; }
         if (ovf) { err |= ERR_CIGAR_CAP; n = 0; }
     }
 #undef TB_PUSH
-    return wave_bcast(n, 0);
+    n = wave_bcast(n, 0);
+    // the reversal across the lanes: the pool is global memory, and one lane swapping the ~3 000 operations of a noisy 10 kb
+    // read pair by pair is ~1 500 dependent round trips (a third of such a job's time when it was written that way)
+    __syncthreads();
+    for (int a = lane; a < n >> 1; a += WAVE) { const uint32_t lo = load_fresh(cigar + a), hi = load_fresh(cigar + (n - 1 - a)); cigar[a] = hi; cigar[n - 1 - a] = lo; }
+    __syncthreads();
+    gclk(K, 8);
+    return n;
 }
 
 // one ksw_global2 call; the raw CIGAR (before clip / deletion squeezing) goes to cigar[0..*n_cigar)
 static __device__ int global_wave(const DevIndex& ix, const MemOpt& opt, const GLds& L, int lane, const SeqAcc& A, int w,
-                                  uint8_t* z, int n_col, uint32_t* cigar, int cig_cap, int* n_cigar, int& err, uint8_t* tile)
+                                  uint8_t* z, bool z_lds, int n_col, uint32_t* cigar, int cig_cap, int* n_cigar, int& err, uint8_t* tile, GClk& K)
 {
     const int RM = L.rm;
     const int qlen = A.qlen, tlen = A.tlen;
@@ -133,7 +157,7 @@ static __device__ int global_wave(const DevIndex& ix, const MemOpt& opt, const G
             hlast = wave_bcast(h, last);
             int Plast = wave_bcast(P, 63);
             { int f1 = fcarry - WAVE * e_ins, f2 = Plast - (c + 63) * e_ins; fcarry = f1 > f2 ? f1 : f2; }
-            if (act) { zi[j - beg] = (uint8_t)d; L.eh_e[j & RM] = e2; L.eh_h[(j + 1) & RM] = h; }
+            if (act) { z_put(zi + (j - beg), (uint8_t)d, z_lds); L.eh_e[j & RM] = e2; L.eh_h[(j + 1) & RM] = h; }
         }
         if (lane == 0) {
             if (end > beg) L.eh_h[beg & RM] = h1i;
@@ -144,7 +168,7 @@ static __device__ int global_wave(const DevIndex& ix, const MemOpt& opt, const G
         __syncthreads();
     }
     const int score = L.eh_h[qlen & RM];
-    *n_cigar = traceback(z, n_col, w, tlen, qlen, lane, cigar, cig_cap, err, tile);
+    *n_cigar = traceback(z, z_lds, n_col, w, tlen, qlen, lane, cigar, cig_cap, err, tile, K);
     __syncthreads();
     return score;
 }
@@ -155,7 +179,7 @@ static __device__ int global_wave(const DevIndex& ix, const MemOpt& opt, const G
 // and the query slides down the lanes one position per row.  Nothing of the DP state lives in LDS and no barrier is
 // needed; only the direction bytes are stored (z, in upstream's [row][column - beg] layout) for the traceback.
 static __device__ int global_wave_diag(const DevIndex& ix, const MemOpt& opt, const uint8_t* sq, int lane, const SeqAcc& A, int w,
-                                       uint8_t* z, int n_col, uint32_t* cigar, int cig_cap, int* n_cigar, int& err, uint8_t* tile)
+                                       uint8_t* z, bool z_lds, int n_col, uint32_t* cigar, int cig_cap, int* n_cigar, int& err, uint8_t* tile, GClk& K)
 {
     const int qlen = A.qlen, tlen = A.tlen;
     const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
@@ -194,14 +218,14 @@ static __device__ int global_wave_diag(const DevIndex& ix, const MemOpt& opt, co
         d |= e2 > t ? 1 << 2 : 0;
         e2 = e2 > t ? e2 : t;
         d |= (f - e_ins) > tins ? 2 << 4 : 0;
-        if (act) z[(int64_t)i * n_col + (lane - lb)] = (uint8_t)d;
+        if (act) z_put(z + ((int64_t)i * n_col + (lane - lb)), (uint8_t)d, z_lds);
         // state of the next row: the lane moves one column to the right along its diagonal
         hd = act ? h : (j == -1 ? -(o_del + e_del * (i + 1)) : MINUS_INF);
         e = dpp_shl1(act ? e2 : MINUS_INF, MINUS_INF);
         qv = dpp_shl1(qv, qin);
     }
     const int score = wave_bcast(h, qlen - 1 - (tlen - 1 - w));     // H(tlen-1, qlen-1); the caller checked that lane is in the band
-    *n_cigar = traceback(z, n_col, w, tlen, qlen, lane, cigar, cig_cap, err, tile);
+    *n_cigar = traceback(z, z_lds, n_col, w, tlen, qlen, lane, cigar, cig_cap, err, tile, K);
     return score;
 }
 
@@ -211,7 +235,7 @@ static __device__ int global_wave_diag(const DevIndex& ix, const MemOpt& opt, co
 // No LDS rows, no barriers: one DPP scan per chunk and row.
 template <int NCH>
 static __device__ int global_wave_diag_n(const DevIndex& ix, const MemOpt& opt, const uint8_t* sq, int lane, const SeqAcc& A, int w,
-                                         uint8_t* z, int n_col, uint32_t* cigar, int cig_cap, int* n_cigar, int& err, uint8_t* tile)
+                                         uint8_t* z, bool z_lds, int n_col, uint32_t* cigar, int cig_cap, int* n_cigar, int& err, uint8_t* tile, GClk& K)
 {
     const int qlen = A.qlen, tlen = A.tlen;
     const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
@@ -261,7 +285,7 @@ static __device__ int global_wave_diag_n(const DevIndex& ix, const MemOpt& opt, 
             d |= e2 > t ? 1 << 2 : 0;
             e2 = e2 > t ? e2 : t;
             d |= (f - e_ins) > tins ? 2 << 4 : 0;
-            if (act) zi[s - lb] = (uint8_t)d;
+            if (act) z_put(zi + (s - lb), (uint8_t)d, z_lds);
             hd[c] = act ? h : (j == -1 ? -(o_del + e_del * (i + 1)) : MINUS_INF);   // the lane moves one column to the right along its diagonal
             hrow[c] = h;
             e2s[c] = act ? e2 : MINUS_INF;
@@ -279,7 +303,7 @@ static __device__ int global_wave_diag_n(const DevIndex& ix, const MemOpt& opt, 
     int score = MINUS_INF;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) if ((l_end >> 6) == c) score = wave_bcast(hrow[c], l_end & 63);
-    *n_cigar = traceback(z, n_col, w, tlen, qlen, lane, cigar, cig_cap, err, tile);
+    *n_cigar = traceback(z, z_lds, n_col, w, tlen, qlen, lane, cigar, cig_cap, err, tile, K);
     return score;
 }
 
@@ -464,6 +488,7 @@ __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView
     }
     uint8_t* z_lds = sq + ((cap + 15) & ~15);
     int err = 0;
+    GClk K; K.c = (tv.debug & 0x2000) ? tv.cnt->dbg : nullptr; K.t = K.c ? clock64() : 0;
     SeqAcc A; A.q = query + ar.qb; A.qlen = ar.qe - ar.qb; A.rev = ar.rb >= ix.l_pac; A.t0 = ar.rb; A.tlen = (int)(ar.re - ar.rb);
     uint32_t* cigar = cig_pool + (size_t)job * cig_cap;
     // the retry loop of mem_reg2aln around bwa_gen_cigar2 (all lanes take the same decisions)
@@ -501,13 +526,14 @@ __global__ void __launch_bounds__(64) k_gcigar(DevIndex ix, MemOpt opt, TileView
             uint8_t* tile = z == z_lds || z_lds_cap < 4096 ? nullptr : z_lds;   // a matrix in global memory is walked through 64 x 64 tiles staged where the small ones live
             const bool diag_ok = l_end >= 0 && l_end <= 2 * w;
             const int nch = (2 * w + 1 + 63) >> 6;
+            if ((tv.debug & 0x8000) && lane == 0) printf("[gcigar] job %d try %d qlen %d tlen %d w2 %d w %d chunks %d truesc %d reg.w %d\n", job, i, l_query, rlen, w2, w, nch, ar.truesc, ar.w);
             if (!HBM && !(diag_ok && nch <= MAXCH) && 2 * w + 4 > ring && l_query + 2 > ring) { deferred = true; break; }   // needs rows longer than the rings
-            if (diag_ok && nch <= 1) score = global_wave_diag(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
-            else if (MAXCH >= 2 && diag_ok && nch <= 2) score = global_wave_diag_n<2>(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
-            else if (MAXCH >= 4 && diag_ok && nch <= 4) score = global_wave_diag_n<4>(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
-            else if (MAXCH >= 7 && diag_ok && nch <= 7) score = global_wave_diag_n<7>(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
-            else if (MAXCH >= 13 && diag_ok && nch <= 13) score = global_wave_diag_n<13>(ix, opt, sq, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
-            else score = global_wave(ix, opt, L, lane, A, w, z, n_col, cigar, cig_cap, &n_cigar, err, tile);
+            if (diag_ok && nch <= 1) score = global_wave_diag(ix, opt, sq, lane, A, w, z, z == z_lds, n_col, cigar, cig_cap, &n_cigar, err, tile, K);
+            else if (MAXCH >= 2 && diag_ok && nch <= 2) score = global_wave_diag_n<2>(ix, opt, sq, lane, A, w, z, z == z_lds, n_col, cigar, cig_cap, &n_cigar, err, tile, K);
+            else if (MAXCH >= 4 && diag_ok && nch <= 4) score = global_wave_diag_n<4>(ix, opt, sq, lane, A, w, z, z == z_lds, n_col, cigar, cig_cap, &n_cigar, err, tile, K);
+            else if (MAXCH >= 7 && diag_ok && nch <= 7) score = global_wave_diag_n<7>(ix, opt, sq, lane, A, w, z, z == z_lds, n_col, cigar, cig_cap, &n_cigar, err, tile, K);
+            else if (MAXCH >= 13 && diag_ok && nch <= 13) score = global_wave_diag_n<13>(ix, opt, sq, lane, A, w, z, z == z_lds, n_col, cigar, cig_cap, &n_cigar, err, tile, K);
+            else score = global_wave(ix, opt, L, lane, A, w, z, z == z_lds, n_col, cigar, cig_cap, &n_cigar, err, tile, K);
             if (score == last_sc || w2 == opt.w << 2) break;
             last_sc = score;
             w2 <<= 1;

@@ -866,6 +866,7 @@ static bool run_tile_se(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwamem_b
         HIP_OK(hipMemcpyAsync(errv, tv.err, sizeof errv, hipMemcpyDeviceToHost, ws.stream));
         HIP_OK(hipStreamSynchronize(ws.stream));
         err = errv[0];
+        if (tv.debug & 0x2000) fprintf(stderr, "[bwamem_hip] global alignment, Mclk summed over waves: rows %.1f tile staging %.1f walk %.1f end %.1f | jobs %d\n", hc.dbg[5] / 1e6, hc.dbg[6] / 1e6, hc.dbg[7] / 1e6, hc.dbg[8] / 1e6, n_jobs);
         if (err) {
             { std::lock_guard<std::mutex> lk(g_stats.mu); ++g_stats.s.n_retries; }
             if (err & ERR_RESCUE_CAP) { if (rescore_full) { fprintf(stderr, "[bwamem_hip] internal error: seed re-scoring list beyond the seed count\n"); return false; } rescore_full = true; continue; }

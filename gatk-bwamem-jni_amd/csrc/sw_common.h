@@ -18,7 +18,7 @@ struct SwIn {
     int qrev;                                     // > 0: the first qrev query bases are read reversed (second pass)
     int64_t t0; int trev;                         // target = reference from t0; the first trev bases reversed (second pass)
 };
-DEV int sw_q0(const SwIn& I, int i) { int c = I.is_rev ? I.ms[I.l_ms - 1 - i] : I.ms[i]; return I.is_rev ? (c < 4 ? 3 - c : 4) : c; }
+DEV int sw_q0(const SwIn& I, int i) { int c = *AS_GLOBAL(const uint8_t, I.ms + (I.is_rev ? I.l_ms - 1 - i : i)); return I.is_rev ? (c < 4 ? 3 - c : 4) : c; }   // (ms: a read of the tile, global memory)
 DEV int sw_q(const SwIn& I, int i) { return sw_q0(I, i < I.qrev ? I.qrev - 1 - i : i); }
 DEV int sw_t(const DevIndex& ix, const SwIn& I, int i) { return ref_base2(ix, I.t0 + (i < I.trev ? I.trev - 1 - i : i)); }
 
@@ -149,8 +149,9 @@ struct SwLds { uint64_t* b; int cap_b; };               // [64 / GW][cap_b] row-
 // alignments one after another while every other wave has finished.  All arguments are per lane but uniform within a group;
 // `on` says whether the group has an alignment at all; `size` (byte or 16-bit mode) is the same for the whole wave.
 template <int NSEG, int GW>
-static __device__ __attribute__((noinline)) KswR sw_core_wave4(const DevIndex& ix, const MemOpt& opt, const SwIn& I, bool on, int size, int qlen, int tlen, int xtra, const SwLds& W, int lane, int& err)
+static __device__ __attribute__((noinline)) KswR sw_core_wave4(const DevIndex& ix, const MemOpt& opt, const SwIn& I, bool on, int size, int qlen, int tlen, int xtra, const SwLds& W, int lane, int& err_out)
 {
+    int err = 0;                                                // (behind the reference it would be a flat access in the row loop)
     static_assert(GW == 16 || GW == 8, "group width");
     const int p = 8 * (3 - size), u8 = size == 1;              // (GW = 8 is for 16-bit mode only: p == GW)
     const int g = lane / GW, sl = lane % GW;
@@ -167,7 +168,10 @@ static __device__ __attribute__((noinline)) KswR sw_core_wave4(const DevIndex& i
     const int endsc = (xtra & KSW_XSTOP) ? xtra & 0xffff : 0x10000;
     const bool la = on && sl < p;                           // this lane is one of upstream's vector lanes of a live group
     const int l = sl < p ? sl : 0;
-    uint64_t* const bl = W.b + (size_t)g * W.cap_b;          // the group's row-maxima list
+    uint64_t* const bl = W.b + (size_t)g * W.cap_b;          // the group's row-maxima list (LDS: said so at every access, see AS_LDS)
+    const int cap_b = W.cap_b, trev = I.trev;
+    const int64_t t0 = I.t0, l_pac = ix.l_pac;
+    const uint8_t* const pac = ix.pac;
     const ScoreTab ST = score_tab(opt);
     int H0[NSEG], H1[NSEG], E[NSEG], Hmax[NSEG], sn[NSEG];
     uint32_t sp[NSEG];
@@ -184,7 +188,7 @@ static __device__ __attribute__((noinline)) KswR sw_core_wave4(const DevIndex& i
     for (int i = 0; ; ++i) {
         const bool run = !stop && i < tlen;
         if (__ballot(run) == 0ull) break;
-        const int tb = run ? ref_base2_c(ix, pc, I.t0 + (i < I.trev ? I.trev - 1 - i : i)) : 0;
+        const int tb = run ? ref_base2_cp(pac, l_pac, pc, t0 + (i < trev ? trev - 1 - i : i)) : 0;
         int f = 0, mx = 0;
         int hlast = 0;
 #pragma unroll
@@ -239,9 +243,9 @@ static __device__ __attribute__((noinline)) KswR sw_core_wave4(const DevIndex& i
         // in registers by every lane (the list itself is only read after the loop), so the rows need no barrier
         if (run && imax >= minsc) {
             if (n_b == 0 || last_i + 1 != i) {
-                if (n_b >= W.cap_b) { err |= ERR_SCRATCH; stop = true; }
-                else { if (sl == 0) bl[n_b] = (uint64_t)imax << 32 | (uint32_t)i; ++n_b; last_i = i; last_sc = imax; }
-            } else if (last_sc < imax) { if (sl == 0) bl[n_b - 1] = (uint64_t)imax << 32 | (uint32_t)i; last_i = i; last_sc = imax; }
+                if (n_b >= cap_b) { err |= ERR_SCRATCH; stop = true; }
+                else { if (sl == 0) *AS_LDS(uint64_t, bl + n_b) = (uint64_t)imax << 32 | (uint32_t)i; ++n_b; last_i = i; last_sc = imax; }
+            } else if (last_sc < imax) { if (sl == 0) *AS_LDS(uint64_t, bl + (n_b - 1)) = (uint64_t)imax << 32 | (uint32_t)i; last_i = i; last_sc = imax; }
         }
         if (run && !stop && imax > gmax) {
             gmax = imax; te = i;
@@ -278,13 +282,15 @@ static __device__ __attribute__((noinline)) KswR sw_core_wave4(const DevIndex& i
                 int i = (r.score + qmax - 1) / qmax;
                 int low = te - i, high = te + i;
                 for (i = 0; i < n_b; ++i) {
-                    int e = (int32_t)bl[i];
-                    if ((e < low || e > high) && (int)(bl[i] >> 32) > r.score2) { r.score2 = (int)(bl[i] >> 32); r.te2 = e; }
+                    const uint64_t be = *AS_LDS(const uint64_t, bl + i);
+                    int e = (int32_t)be;
+                    if ((e < low || e > high) && (int)(be >> 32) > r.score2) { r.score2 = (int)(be >> 32); r.te2 = e; }
                 }
             }
         }
     }
     __syncthreads();
+    if (err) err_out |= err;
     return r;
 }
 
@@ -318,8 +324,9 @@ DEV KswR sw_align2_wave4(const DevIndex& ix, const MemOpt& opt, SwIn I, bool on,
 struct SwPair { SwIn I[2]; bool on[2]; int qlen[2], tlen[2], xtra[2]; };
 
 template <int NSEG, bool U8>
-static __device__ __attribute__((noinline)) void sw_core_packed(const DevIndex& ix, const MemOpt& opt, const SwPair& P, const SwLds& W, int lane, int& err, KswR R[2])
+static __device__ __attribute__((noinline)) void sw_core_packed(const DevIndex& ix, const MemOpt& opt, const SwPair& P, const SwLds& W, int lane, int& err_out, KswR R[2])
 {
+    int err = 0;
     constexpr int GW = U8 ? 16 : 8;
     const int g = lane / GW, sl = lane % GW;
     const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
@@ -329,7 +336,13 @@ static __device__ __attribute__((noinline)) void sw_core_packed(const DevIndex& 
     const int bias = U8 ? shift : 128;                           // what is added to a score to make it an unsigned byte
     const uint32_t BIAS = pk_both(bias), C255 = pk_both(255), OED = pk_both(o_del + e_del), ED = pk_both(e_del), OEI = pk_both(o_ins + e_ins), EI = pk_both(e_ins);
     int slen[2], n_b[2] = { 0, 0 }, te[2] = { -1, -1 }, gmax[2] = { 0, 0 }, minsc[2], endsc[2], last_i[2] = { -2, -2 }, last_sc[2] = { 0, 0 };
-    bool stop[2];
+    int tlen[2], trev[2], qlen[2];                               // (P and W are read once: they sit behind references the row loop's stores might alias)
+    int64_t t0[2];
+    const int cap_b = W.cap_b;
+    const int64_t l_pac = ix.l_pac;
+    const uint8_t* const pac = ix.pac;
+    bool stop[2], on[2];
+    SwIn Il[2];
     uint64_t* bl[2];
     PacCache pc[2];
 #pragma unroll
@@ -337,8 +350,9 @@ static __device__ __attribute__((noinline)) void sw_core_packed(const DevIndex& 
         slen[h] = P.on[h] ? (P.qlen[h] + GW - 1) / GW : 0;
         minsc[h] = (P.xtra[h] & KSW_XSUBO) ? P.xtra[h] & 0xffff : 0x10000;
         endsc[h] = (P.xtra[h] & KSW_XSTOP) ? P.xtra[h] & 0xffff : 0x10000;
-        stop[h] = !P.on[h];
-        bl[h] = W.b + (size_t)(g * 2 + h) * W.cap_b;
+        stop[h] = !P.on[h]; on[h] = P.on[h];
+        tlen[h] = P.tlen[h]; qlen[h] = P.qlen[h]; Il[h] = P.I[h]; trev[h] = Il[h].trev; t0[h] = Il[h].t0;
+        bl[h] = W.b + (size_t)(g * 2 + h) * W.cap_b;             // LDS: said so at every access (AS_LDS)
         pc[h].w = -1; pc[h].v = 0;
         R[h].score = 0; R[h].te = R[h].qe = R[h].score2 = R[h].te2 = R[h].tb = R[h].qb = -1;
     }
@@ -351,9 +365,9 @@ static __device__ __attribute__((noinline)) void sw_core_packed(const DevIndex& 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int pos = j + sl * slen[h];
-            const bool pad = !(P.on[h] && j < slen[h] && pos < P.qlen[h]);
+            const bool pad = !(on[h] && j < slen[h] && pos < qlen[h]);
             uint32_t sp; int sn;
-            score_lane(ST, pad ? 4 : sw_q(P.I[h], pos), sp, sn);
+            score_lane(ST, pad ? 4 : sw_q(Il[h], pos), sp, sn);
             // score + bias per target base as unsigned bytes; a pad position scores 0 against everything
             uint32_t w = 0;
 #pragma unroll
@@ -368,8 +382,8 @@ static __device__ __attribute__((noinline)) void sw_core_packed(const DevIndex& 
         uint32_t tb[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            run[h] = !stop[h] && i < P.tlen[h];
-            tb[h] = run[h] ? (uint32_t)ref_base2_c(ix, pc[h], P.I[h].t0 + (i < P.I[h].trev ? P.I[h].trev - 1 - i : i)) : 0u;
+            run[h] = !stop[h] && i < tlen[h];
+            tb[h] = run[h] ? (uint32_t)ref_base2_cp(pac, l_pac, pc[h], t0[h] + (i < trev[h] ? trev[h] - 1 - i : i)) : 0u;
         }
         if (__ballot(run[0] || run[1]) == 0ull) break;
         const uint32_t runm = (run[0] ? 0xffffu : 0u) | (run[1] ? 0xffff0000u : 0u);
@@ -419,9 +433,9 @@ static __device__ __attribute__((noinline)) void sw_core_packed(const DevIndex& 
             const int im = pk_half(imax, hf);
             if (run[hf] && im >= minsc[hf]) {                   // (the last listed row lives in registers: see sw_core_wave4)
                 if (n_b[hf] == 0 || last_i[hf] + 1 != i) {
-                    if (n_b[hf] >= W.cap_b) { err |= ERR_SCRATCH; stop[hf] = true; }
-                    else { if (sl == 0) bl[hf][n_b[hf]] = (uint64_t)im << 32 | (uint32_t)i; ++n_b[hf]; last_i[hf] = i; last_sc[hf] = im; }
-                } else if (last_sc[hf] < im) { if (sl == 0) bl[hf][n_b[hf] - 1] = (uint64_t)im << 32 | (uint32_t)i; last_i[hf] = i; last_sc[hf] = im; }
+                    if (n_b[hf] >= cap_b) { err |= ERR_SCRATCH; stop[hf] = true; }
+                    else { if (sl == 0) *AS_LDS(uint64_t, bl[hf] + n_b[hf]) = (uint64_t)im << 32 | (uint32_t)i; ++n_b[hf]; last_i[hf] = i; last_sc[hf] = im; }
+                } else if (last_sc[hf] < im) { if (sl == 0) *AS_LDS(uint64_t, bl[hf] + (n_b[hf] - 1)) = (uint64_t)im << 32 | (uint32_t)i; last_i[hf] = i; last_sc[hf] = im; }
             }
         }
 #pragma unroll
@@ -442,7 +456,7 @@ static __device__ __attribute__((noinline)) void sw_core_packed(const DevIndex& 
     __syncthreads();
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-        KswR& r = R[hf];
+        KswR r; r.qe = r.score2 = r.te2 = r.tb = r.qb = -1;    // (a local: R sits behind a pointer, and the list walk below updates score2 / te2 per entry)
         r.score = U8 ? (gmax[hf] + shift < 255 ? gmax[hf] : 255) : gmax[hf];
         r.te = te[hf];
         int best = -1, bq = 0x7fffffff;
@@ -457,19 +471,22 @@ static __device__ __attribute__((noinline)) void sw_core_packed(const DevIndex& 
             const int ub = __shfl_xor(best, o), uq = __shfl_xor(bq, o);
             if (ub > best || (ub == best && uq < bq)) { best = ub; bq = uq; }
         }
-        if (P.on[hf] && (!U8 || r.score != 255)) {
+        if (on[hf] && (!U8 || r.score != 255)) {
             r.qe = bq;
             if (n_b[hf] > 0) {
                 int i = (r.score + qmax - 1) / qmax;
                 const int low = te[hf] - i, high = te[hf] + i;
                 for (i = 0; i < n_b[hf]; ++i) {
-                    const int e = (int32_t)bl[hf][i];
-                    if ((e < low || e > high) && (int)(bl[hf][i] >> 32) > r.score2) { r.score2 = (int)(bl[hf][i] >> 32); r.te2 = e; }
+                    const uint64_t be = *AS_LDS(const uint64_t, bl[hf] + i);
+                    const int e = (int32_t)be;
+                    if ((e < low || e > high) && (int)(be >> 32) > r.score2) { r.score2 = (int)(be >> 32); r.te2 = e; }
                 }
             }
         }
+        R[hf] = r;
     }
     __syncthreads();
+    if (err) err_out |= err;
 }
 
 // ksw_align2 for the sixteen (byte mode: eight) alignments of a wavefront, two per group of GW lanes; P per lane, uniform within a group
