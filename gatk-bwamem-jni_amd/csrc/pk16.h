@@ -40,6 +40,24 @@ DEV uint32_t pk_sra15(uint32_t a) { return (a & 0x8000u ? 0xffffu : 0u) | (a & 0
 DEV uint32_t pk_subs(uint32_t a, uint32_t b) { const uint32_t al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16; return (al > bl ? al - bl : 0u) | (ah > bh ? ah - bh : 0u) << 16; }
 DEV uint32_t pk_bytes2(uint32_t lo, uint32_t hi, uint32_t klo, uint32_t khi) { return (lo >> (8 * klo) & 0xffu) | (hi >> (8 * khi) & 0xffu) << 16; }
 #endif
+// ---- the same in every build: pieces the banded global alignment (k_cigar.hip: global_wave_diag_pk) adds
+#if defined(__HIP_DEVICE_COMPILE__)
+DEV uint32_t pk_maxu(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pk_u16_t, a), __builtin_bit_cast(pk_u16_t, b))); }
+// signed a - b / a + b per half, saturating at -32768 / 32767 (the clamp bit)
+DEV uint32_t pk_subss(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEV uint32_t pk_addss(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// bytes 0 and 2 of the result picked from the eight bytes {s1 (selectors 0..3), s0 (4..7)} by bytes 0 and 2 of sel; bytes 1 and 3 of sel are 0x0c (zero)
+DEV uint32_t pk_perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+#else
+DEV uint32_t pk_maxu(uint32_t a, uint32_t b) { const uint32_t al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16; return (al > bl ? al : bl) | (ah > bh ? ah : bh) << 16; }
+DEV int pk_sat16_(int x) { return x < -32768 ? -32768 : x > 32767 ? 32767 : x; }
+DEV uint32_t pk_subss(uint32_t a, uint32_t b) { return (uint32_t)(uint16_t)pk_sat16_((int)(int16_t)(a & 0xffffu) - (int)(int16_t)(b & 0xffffu)) | (uint32_t)(uint16_t)pk_sat16_((int)(int16_t)(a >> 16) - (int)(int16_t)(b >> 16)) << 16; }
+DEV uint32_t pk_addss(uint32_t a, uint32_t b) { return (uint32_t)(uint16_t)pk_sat16_((int)(int16_t)(a & 0xffffu) + (int)(int16_t)(b & 0xffffu)) | (uint32_t)(uint16_t)pk_sat16_((int)(int16_t)(a >> 16) + (int)(int16_t)(b >> 16)) << 16; }
+DEV uint32_t pk_perm_byte_(uint32_t s0, uint32_t s1, uint32_t k) { return k < 4 ? (s1 >> (8 * k)) & 0xffu : k < 8 ? (s0 >> (8 * (k - 4))) & 0xffu : 0u; }
+DEV uint32_t pk_perm(uint32_t s0, uint32_t s1, uint32_t sel) { return pk_perm_byte_(s0, s1, sel & 0xffu) | pk_perm_byte_(s0, s1, (sel >> 16) & 0xffu) << 16; }
+#endif
+// signed value of one half
+DEV int pk_shalf(uint32_t a, int h) { return (int)(int16_t)(h ? a >> 16 : a & 0xffffu); }
 // byte k of lo and of hi (k = 0..3)
 DEV uint32_t pk_bytes(uint32_t lo, uint32_t hi, int k) { return pk_bytes2(lo, hi, (uint32_t)k, (uint32_t)k); }
 // both halves = the 16 low bits of x / the two halves from two ints

@@ -8,6 +8,7 @@
 #include <vector>
 #include "../../gatk-bwamem-jni_amd/csrc/k_extend.hip"
 #include "../../gatk-bwamem-jni_amd/csrc/k_pe.hip"
+#include "../../gatk-bwamem-jni_amd/csrc/k_cigar.hip"
 #include "../../gatk-bwamem-jni_amd/csrc/chain_flt.h"
 #include "../../gatk-bwamem-jni_amd/csrc/post_common.h"
 
@@ -238,4 +239,81 @@ extern "C" int unit_sw_jobs(const MemOpt* opt, int n, const uint8_t* queries, co
     hipMemcpy(out, d_res, (size_t)n * sizeof(KswR), hipMemcpyDeviceToHost);
     hipFree(d_pac); hipFree(d_seq); hipFree(d_off); hipFree(d_err); hipFree(d_cnt); hipFree(d_jobs); hipFree(d_res);
     return rc ? rc : e;
+}
+
+
+// ksw_global2 as k_gcigar's wave forms run it: job i = query i (codes 0..4) against tlen[i] reference bases from toff[i] of a
+// throw-away packed "reference" with band w[i]; the direction matrix of a job in its own stretch of global memory, walked through
+// tiles staged in LDS (what long reads do).  mode 0: the 32-bit diagonal forms; mode 1: the packed 16-bit form where its fit test
+// accepts the job (out_ok = 1), the 32-bit form otherwise (out_ok = 0: refused up front, 2: gave up at a range check).
+// range_override > 0 replaces the fit test's range (to drive the give-up path).  out: score, n_cigar per job; cigars [n][cig_cap]
+__global__ void __launch_bounds__(64) k_unit_global(DevIndex ix, MemOpt opt, const uint8_t* queries, const int64_t* qoff, const int64_t* toff, const int32_t* tlen, const int32_t* wv,
+                                                    int mode, int range_override, uint8_t* zall, const int64_t* zoff, uint32_t* cig, int cig_cap, int32_t* out, int max_q)
+{
+    HIP_DYNAMIC_SHARED(int32_t, smem)
+    const int lane = threadIdx.x, job = blockIdx.x;
+    uint8_t* sq = (uint8_t*)smem;
+    uint8_t* tile = sq + ((max_q + 2 + 15) & ~15);
+    SeqAcc A; A.q = queries + qoff[job]; A.qlen = (int)(qoff[job + 1] - qoff[job]); A.rev = 0; A.t0 = toff[job]; A.tlen = tlen[job];
+    const int w = wv[job];
+    for (int j = lane; j < A.qlen; j += WAVE) sq[j] = (uint8_t)acc_q(A, j);
+    __syncthreads();
+    const int n_col = A.qlen < 2 * w + 1 ? A.qlen : 2 * w + 1, nch = (2 * w + 1 + 63) >> 6;
+    uint8_t* z = zall + zoff[job];
+    int score = 0, okc = 0, err = 0, n_cigar = 0;
+    bool done = false;
+    GpkFit fit;
+    if (mode == 1 && nch >= 2 && nch <= 14 && gpk_fit(opt, w, (nch + 1) >> 1, fit)) {
+        if (range_override > 0) fit.range = range_override;
+        if (nch <= 2) score = global_wave_diag_pk<1>(ix, opt, sq, lane, A, w, fit, z, false, n_col, done);
+        else if (nch <= 4) score = global_wave_diag_pk<2>(ix, opt, sq, lane, A, w, fit, z, false, n_col, done);
+        else if (nch <= 8) score = global_wave_diag_pk<4>(ix, opt, sq, lane, A, w, fit, z, false, n_col, done);
+        else score = global_wave_diag_pk<7>(ix, opt, sq, lane, A, w, fit, z, false, n_col, done);
+        okc = done ? 1 : 2;
+    }
+    if (!done) {
+        if (nch <= 1) score = global_wave_diag(ix, opt, sq, lane, A, w, z, false, n_col);
+        else if (nch <= 2) score = global_wave_diag_n<2>(ix, opt, sq, lane, A, w, z, false, n_col);
+        else if (nch <= 4) score = global_wave_diag_n<4>(ix, opt, sq, lane, A, w, z, false, n_col);
+        else if (nch <= 7) score = global_wave_diag_n<7>(ix, opt, sq, lane, A, w, z, false, n_col);
+        else score = global_wave_diag_n<13>(ix, opt, sq, lane, A, w, z, false, n_col);
+    }
+    GClk K; K.c = nullptr; K.t = 0;
+    n_cigar = traceback(z, false, n_col, w, A.tlen, A.qlen, lane, cig + (size_t)job * cig_cap, cig_cap, err, tile, K);
+    if (lane == 0) { out[4 * job] = score; out[4 * job + 1] = n_cigar; out[4 * job + 2] = okc; out[4 * job + 3] = err; }
+}
+
+extern "C" int unit_global(const MemOpt* opt, int n, const uint8_t* queries, const int64_t* qoff, const uint8_t* target, int64_t l_target,
+                           const int64_t* toff, const int32_t* tlen, const int32_t* w, int mode, int range_override, int cig_cap, int32_t* out, uint32_t* cigars)
+{
+    std::vector<uint8_t> pac((size_t)l_target / 4 + 2, 0);
+    for (int64_t i = 0; i < l_target; ++i) pac[i >> 2] |= (uint8_t)((target[i] & 3) << ((~i & 3) << 1));
+    std::vector<int64_t> zoff((size_t)n + 1, 0);
+    int max_q = 0;
+    for (int i = 0; i < n; ++i) {
+        const int ql = (int)(qoff[i + 1] - qoff[i]);
+        max_q = ql > max_q ? ql : max_q;
+        zoff[i + 1] = zoff[i] + (((int64_t)(2 * w[i] + 1) * tlen[i] + 255) & ~(int64_t)255);
+    }
+    uint8_t *d_pac, *d_seq, *d_z; int64_t *d_qoff, *d_toff, *d_zoff; int32_t *d_tlen, *d_w, *d_out; uint32_t* d_cig;
+    hipMalloc((void**)&d_pac, pac.size()); hipMalloc((void**)&d_seq, (size_t)qoff[n] + 64); hipMalloc((void**)&d_z, (size_t)zoff[n] + 256);
+    hipMalloc((void**)&d_qoff, ((size_t)n + 1) * 8); hipMalloc((void**)&d_toff, (size_t)n * 8 + 8); hipMalloc((void**)&d_zoff, ((size_t)n + 1) * 8);
+    hipMalloc((void**)&d_tlen, (size_t)n * 4 + 4); hipMalloc((void**)&d_w, (size_t)n * 4 + 4); hipMalloc((void**)&d_out, (size_t)n * 16 + 16); hipMalloc((void**)&d_cig, (size_t)n * cig_cap * 4 + 16);
+    hipMemcpy(d_pac, pac.data(), pac.size(), hipMemcpyHostToDevice);
+    hipMemcpy(d_seq, queries, (size_t)qoff[n], hipMemcpyHostToDevice);
+    hipMemcpy(d_qoff, qoff, ((size_t)n + 1) * 8, hipMemcpyHostToDevice);
+    hipMemcpy(d_toff, toff, (size_t)n * 8, hipMemcpyHostToDevice);
+    hipMemcpy(d_zoff, zoff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice);
+    hipMemcpy(d_tlen, tlen, (size_t)n * 4, hipMemcpyHostToDevice);
+    hipMemcpy(d_w, w, (size_t)n * 4, hipMemcpyHostToDevice);
+    hipMemset(d_out, 0, (size_t)n * 16);
+    DevIndex ix; memset(&ix, 0, sizeof ix);
+    ix.pac = d_pac; ix.l_pac = l_target;
+    const size_t shmem = (((size_t)max_q + 2 + 15) & ~(size_t)15) + 4096 + 64;
+    hipLaunchKernelGGL(k_unit_global, dim3(n), dim3(64), shmem, 0, ix, *opt, d_seq, d_qoff, d_toff, d_tlen, d_w, mode, range_override, d_z, d_zoff, d_cig, cig_cap, d_out, max_q);
+    int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+    hipMemcpy(out, d_out, (size_t)n * 16, hipMemcpyDeviceToHost);
+    hipMemcpy(cigars, d_cig, (size_t)n * cig_cap * 4, hipMemcpyDeviceToHost);
+    hipFree(d_pac); hipFree(d_seq); hipFree(d_z); hipFree(d_qoff); hipFree(d_toff); hipFree(d_zoff); hipFree(d_tlen); hipFree(d_w); hipFree(d_out); hipFree(d_cig);
+    return rc;
 }

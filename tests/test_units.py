@@ -416,3 +416,85 @@ def test_units_emu_extend_long(oracle):
 @pytest.mark.gpu
 def test_units_gpu_extend_long(oracle):
     _check_extend_long(_load("hip"), oracle, 120, 6000)
+
+
+def _check_global(units, oracle, n_jobs, max_len, seed=23):
+    """ksw_global2 with traceback as k_gcigar's wave forms run it (band across the lanes, one diagonal per slot): the 32-bit form and
+    the packed 16-bit form (two chunks per instruction stream, values re-based every 64 rows) against the oracle's o_ksw_global2 --
+    score and CIGAR; related and unrelated sequences (scores far below zero: the re-basing), N bases, bands of 33 to 401 columns
+    either side, three option sets (bwa's default, -x ont2d's, one the packed form must refuse), and the give-up path of the range check"""
+    og = oracle.dll.o_ksw_global2
+    og.restype = ctypes.c_int
+    og.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p] + [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.POINTER(ctypes.c_uint32))]
+    libc = ctypes.CDLL(None)
+    libc.free.argtypes = [ctypes.c_void_p]
+    units.unit_global.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2
+    rng = np.random.default_rng(seed)
+    target = rng.integers(0, 4, size=max_len * 4 + 4000, dtype=np.uint8)
+    for oi, (a, b, o, e) in enumerate([(1, 4, 6, 1), (1, 1, 1, 1), (2, 20, 30, 3)]):
+        scmat = [(a if i == j else -b) if i < 4 and j < 4 else -1 for i in range(5) for j in range(5)]     # bwa_fill_scmat
+        opts = B.set_opt(oracle.default_options(), a=a, b=b, o_del=o, e_del=e, o_ins=o, e_ins=e, mat=scmat)
+        ob = ctypes.create_string_buffer(bytes(opts), 168)
+        mat = bytes(opts[140:165])
+        qs, qoff, toff, tlen, wv = [], [0], [], [], []
+        for it in range(n_jobs):
+            w = int(rng.choice([16, 33, 50, 100, 100, 100, 150, 200, 400]))
+            tl = int(rng.integers(40, max_len)) if it % 3 else int(rng.integers(max_len // 2, max_len))
+            t0 = int(rng.integers(0, len(target) - tl))
+            t = target[t0: t0 + tl]
+            if it % 6 == 5:                                                             # unrelated: the score sinks by ~3 a row
+                q = rng.integers(0, 4, size=max(8, tl + int(rng.integers(-w // 3, w // 3 + 1))), dtype=np.uint8)
+            else:                                                                       # a noisy copy: substitutions, N, single-base and longer indels
+                sub, ind = rng.choice([0.0, 0.02, 0.08, 0.15]), rng.choice([0.0, 0.005, 0.03])
+                out = []
+                j = 0
+                while j < tl:
+                    r = rng.random()
+                    if r < ind: out.append(int(rng.integers(0, 4)))                    # insertion
+                    elif r < 2 * ind: j += 1 + (int(rng.integers(0, 12)) if rng.random() < 0.1 else 0)   # deletion
+                    else:
+                        c = int(t[j]); j += 1
+                        if rng.random() < sub: c = int(rng.integers(0, 5))
+                        out.append(c)
+                q = np.asarray(out[: tl + w // 2] if len(out) > 8 else [0] * 9, dtype=np.uint8)
+                if len(q) < tl - w // 2: q = np.concatenate([q, rng.integers(0, 4, size=tl - w // 2 - len(q), dtype=np.uint8)])
+            d = abs(len(q) - tl)
+            w = max(w, d + 3)                                                           # bwa_gen_cigar2 never asks for less
+            if (2 * w + 1 + 63) // 64 > 13: w = 400
+            if abs(len(q) - tl) > w: q = np.resize(q, tl)
+            qs.append(q); qoff.append(qoff[-1] + len(q)); toff.append(t0); tlen.append(tl); wv.append(w)
+        qcat = np.concatenate(qs).astype(np.uint8)
+        qoffa, toffa, tlena, wva = (np.asarray(v, dtype=t) for v, t in ((qoff, np.int64), (toff, np.int64), (tlen, np.int32), (wv, np.int32)))
+        cap = 2 * max_len + 16
+        want = []
+        for i in range(n_jobs):
+            nc = ctypes.c_int(0); cg = ctypes.POINTER(ctypes.c_uint32)()
+            sc = og(len(qs[i]), qs[i].tobytes(), int(tlen[i]), target[toff[i]: toff[i] + tlen[i]].tobytes(), 5, mat, o, e, o, e, int(wv[i]), ctypes.byref(nc), ctypes.byref(cg))
+            want.append((sc, [cg[k] for k in range(nc.value)]))
+            libc.free(cg)
+        for mode, rng_over in ((0, 0), (1, 0), (1, 40)):
+            out = np.zeros((n_jobs, 4), dtype=np.int32)
+            cig = np.zeros((n_jobs, cap), dtype=np.uint32)
+            rc = units.unit_global(ob, n_jobs, qcat.ctypes.data, qoffa.ctypes.data, target.ctypes.data, len(target), toffa.ctypes.data, tlena.ctypes.data, wva.ctypes.data,
+                                   mode, rng_over, cap, out.ctypes.data, cig.ctypes.data)
+            assert rc == 0, rc
+            for i in range(n_jobs):
+                got = (int(out[i, 0]), cig[i, : out[i, 1]].tolist())
+                assert out[i, 3] == 0 and got == want[i], (oi, mode, rng_over, i, len(qs[i]), int(tlen[i]), int(wv[i]), out[i].tolist(), got[0], want[i][0], got[1][:8], want[i][1][:8])
+            nch = (2 * wva + 1 + 63) // 64
+            if mode == 1 and oi < 2 and rng_over == 0:
+                assert (out[nch >= 2, 2] == 1).all(), (oi, out[:, 2].tolist())          # the packed form took every job it is built for
+            if mode == 1 and oi == 2:
+                assert (out[:, 2] == 0).all()                                            # penalties this large: refused up front
+            if mode == 1 and rng_over:
+                assert oi == 2 or (out[nch >= 2, 2] == 2).any()                          # a 40-point range: most jobs give up at a check and run the 32-bit form
+
+
+def test_units_emu_global(oracle):
+    _check_global(_load("emu"), oracle, 10, 420)
+
+
+@pytest.mark.gpu
+def test_units_gpu_global(oracle):
+    _check_global(_load("hip"), oracle, 240, 2600)
+    _check_global(_load("hip"), oracle, 12, 12000, seed=5)
