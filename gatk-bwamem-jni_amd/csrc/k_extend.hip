@@ -752,6 +752,9 @@ static __device__ bool extend_diag(const DevIndex& ix, const MemOpt& opt, const 
 }
 
 // picks the register-resident form when the query fits
+// SHORT: the caller knows that every query fits the register forms (tiles of reads of at most 3 * 64 - 1 bases): the forms with
+// rows in LDS are then not compiled into the kernel at all -- it is the kernel's hungriest path that sets its register count
+template <bool SHORT = false>
 static __device__ ExtRes extend_any(const DevIndex& ix, const MemOpt& opt, const ExtLds& L, int lane,
                                     int qlen, int q0, int qstep, int tlen, int64_t t0, int tstep,
                                     int w, int end_bonus, int zdrop, int h0, unsigned long long& n_cells, bool try_diag, bool pk2 = true)
@@ -760,7 +763,7 @@ static __device__ ExtRes extend_any(const DevIndex& ix, const MemOpt& opt, const
     if (qlen + 1 <= WAVE) return extend_wave_reg<1>(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
     if (pk2 && extend_pk2_ok(opt, qlen, h0, score_max(opt))) return extend_wave_pk2(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
     if (qlen + 1 <= 2 * WAVE) return extend_wave_reg<2>(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
-    if (qlen + 1 <= 3 * WAVE) return extend_wave_reg<3>(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
+    if (SHORT || qlen + 1 <= 3 * WAVE) return extend_wave_reg<3>(ix, opt, L.query, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
     if (pk2 && L.rm != 0x7fffffff && extend_pkl_ok(opt, L.rm + 1, qlen, w, h0, score_max(opt)))
         return extend_wave_pkl(ix, opt, L, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
     return extend_wave(ix, opt, L, lane, qlen, q0, qstep, tlen, t0, tstep, w, end_bonus, zdrop, h0, n_cells);
@@ -789,7 +792,7 @@ static __host__ __device__ inline int extend_ring(const MemOpt& opt, int max_len
 // HBM = false: one workgroup per read, the rows of the general DP form in LDS (every read up to ~12 000 bases).
 // HBM = true: reads whose rows do not fit a CU's LDS -- a bounded grid walks the reads and each workgroup keeps its rows in
 // its own slice of tv.dp_rows (global memory; only the read itself stays in LDS).  Same code, same results, slower rows.
-template <bool HBM>
+template <bool HBM, bool SHORT = false>
 static __device__ __forceinline__ void extend_read(const DevIndex& ix, const MemOpt& opt, const TileView& tv, int32_t* smem, const int r, const int lane)
 {
     const int64_t s0 = tv.seed_off[r];
@@ -907,7 +910,7 @@ static __device__ __forceinline__ void extend_read(const DevIndex& ix, const Mem
                 for (i = 0; i < MAX_BAND_TRY; ++i) {
                     int prev = a.score;
                     aw0 = opt.w << i;
-                    e = extend_any(ix, opt, L, lane, s.qbeg, s.qbeg - 1, -1, (int)tmp, s.rbeg - 1, -1,
+                    e = extend_any<SHORT>(ix, opt, L, lane, s.qbeg, s.qbeg - 1, -1, (int)tmp, s.rbeg - 1, -1,
                                     aw0, opt.pen_clip5, opt.zdrop, s.len * opt.a, n_cells, try_diag);
                     a.score = e.score;
                     if (a.score == prev || e.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
@@ -928,7 +931,7 @@ static __device__ __forceinline__ void extend_read(const DevIndex& ix, const Mem
                 for (i = 0; i < MAX_BAND_TRY; ++i) {
                     int prev = a.score;
                     aw1 = opt.w << i;
-                    e = extend_any(ix, opt, L, lane, l_query - qe, qe, 1, (int)(rmax1 - rmax0 - re), rmax0 + re, 1,
+                    e = extend_any<SHORT>(ix, opt, L, lane, l_query - qe, qe, 1, (int)(rmax1 - rmax0 - re), rmax0 + re, 1,
                                     aw1, opt.pen_clip3, opt.zdrop, sc0, n_cells, try_diag);
                     a.score = e.score;
                     if (a.score == prev || e.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
@@ -974,6 +977,13 @@ __global__ void __launch_bounds__(64, K_EXTEND_MIN_WAVES) k_extend(DevIndex ix, 
     }
 }
 
+// Tiles of reads of at most 191 bases (every query takes a register form): the same kernel without the LDS forms
+__global__ void __launch_bounds__(64, K_EXTEND_MIN_WAVES) k_extend_short(DevIndex ix, MemOpt opt, TileView tv)
+{
+    HIP_DYNAMIC_SHARED(int32_t, smem)
+    extend_read<false, true>(ix, opt, tv, smem, tv.order ? tv.order[blockIdx.x] : (int)blockIdx.x, threadIdx.x);
+}
+
 // Tiles whose reads keep rows in LDS (beyond 191 bases): the rows and the staged read bound the resident waves (16 KB per
 // 10 kb read: two or three waves per SIMD), so the register allocator gets that room -- 144 registers and no spills instead
 // of 64 with 92 spilled (k_extend 2.55 -> 2.30 s per 200 k reads of 10 kb).
@@ -1000,7 +1010,7 @@ void launch_extend(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const 
     }
     // every query of a tile whose reads are at most 3 * 64 - 1 bases long takes the register form: no rows in LDS, only the
     // read -- which matters for overlap, because k_seed fills the CUs' LDS and a workgroup that asks for 2 KB finds no room
-    if (tv.max_len + 1 <= 3 * WAVE) { hipLaunchKernelGGL(k_extend<false>, dim3(tv.n_reads), dim3(64), ((size_t)tv.max_len + 2 + 15) & ~(size_t)15, st, ix, opt, tv); return; }
+    if (tv.max_len + 1 <= 3 * WAVE) { hipLaunchKernelGGL(k_extend_short, dim3(tv.n_reads), dim3(64), ((size_t)tv.max_len + 2 + 15) & ~(size_t)15, st, ix, opt, tv); return; }
     const size_t shmem = extend_lds_bytes(opt, tv.max_len);
     if (shmem >= 8192) hipLaunchKernelGGL(k_extend_long, dim3(tv.n_reads), dim3(64), shmem, st, ix, opt, tv);
     else hipLaunchKernelGGL(k_extend<false>, dim3(tv.n_reads), dim3(64), shmem, st, ix, opt, tv);

@@ -491,7 +491,7 @@ def _check_global(units, oracle, n_jobs, max_len, seed=23):
 
 
 def test_units_emu_global(oracle):
-    _check_global(_load("emu"), oracle, 10, 420)
+    _check_global(_load("emu"), oracle, 6, 300)
 
 
 @pytest.mark.gpu
