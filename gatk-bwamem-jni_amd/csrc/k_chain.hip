@@ -159,8 +159,9 @@ DEV int test_and_merge(const MemOpt& opt, int64_t l_pac, Chain& c, Seed* seeds, 
     return 0;
 }
 
-DEV int chain_weight(const Chain& c, const Seed* seeds)
+DEV int chain_weight(const Chain& c_, const Seed* seeds)
 {
+    struct { int n, seed0; } c; c.n = c_.n; c.seed0 = c_.seed0;      // (read once: the loops below would otherwise reload them through the reference)
     int64_t end = 0;
     int w = 0, tmp, j, si;
     for (j = 0, si = c.seed0; j < c.n; ++j, si = seeds[si].next) {
@@ -274,7 +275,9 @@ __global__ void __launch_bounds__(64, 8) k_chain(DevIndex ix, MemOpt opt, TileVi
         if (s1 > s0) n_chn = chain_build(ix, opt, tv, chain_store, r, s0, s1, node0);
     }
     Chain* a = tv.chains + s0;
-    int4* kept = (int4*)(((uintptr_t)(tv.bt_nodes + node0 * BT_NODE_INTS) + 15) & ~(uintptr_t)15);
+    // (aligned by pointer arithmetic: through an integer the pointer would lose its address space and every access become a flat one)
+    int32_t* const kept_raw = tv.bt_nodes + node0 * BT_NODE_INTS;
+    int4* kept = (int4*)((char*)kept_raw + ((16 - (int)((uintptr_t)kept_raw & 15)) & 15));
 
     // ---- mem_chain_flt's overlap loop: quadratic in the chains of a read, so reads with many chains get the wavefront, one
     // after the other, and the rest a lane each
@@ -284,7 +287,8 @@ __global__ void __launch_bounds__(64, 8) k_chain(DevIndex ix, MemOpt opt, TileVi
         const int src = __ffsll((long long)heavy) - 1;
         const int64_t s0w = __shfl(s0, src), node0w = __shfl(node0, src);
         const int nw = __shfl(n_chn, src);
-        const int got = chain_flt_wave(opt, seeds, tv.chains + s0w, nw, (int4*)(((uintptr_t)(tv.bt_nodes + node0w * BT_NODE_INTS) + 15) & ~(uintptr_t)15));
+        int32_t* const kw = tv.bt_nodes + node0w * BT_NODE_INTS;
+        const int got = chain_flt_wave(opt, seeds, tv.chains + s0w, nw, (int4*)((char*)kw + ((16 - (int)((uintptr_t)kw & 15)) & 15)));
         if (lane == src) n_kept = got;
     }
     if (n_chn == 0) return;
