@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(64) k_pe_rescue_sw(DevIndex ix, MemOpt opt, Ti
 // the same with two alignments per lane (sw_common.h: sw_core_packed): byte-mode jobs (U8) of LO < segments <= NSEG eight per
 // wavefront, 16-bit jobs sixteen; leaves every other job alone
 template <int LO, int NSEG, bool U8>
-__global__ void __launch_bounds__(64) k_pe_rescue_sw2(DevIndex ix, MemOpt opt, TileView tv, const RescueJob* jobs, const int32_t* counter, int cap, KswR* results, int cap_b)
+__global__ void __launch_bounds__(64, NSEG <= 16 ? 2 : 1) k_pe_rescue_sw2(DevIndex ix, MemOpt opt, TileView tv, const RescueJob* jobs, const int32_t* counter, int cap, KswR* results, int cap_b)
 {
     HIP_DYNAMIC_SHARED(uint64_t, blists)
     constexpr int GW = U8 ? 16 : 8, PER = 2 * (64 / GW);

@@ -14,7 +14,7 @@
 // in flight for this latency-bound stage -- with lane 0 doing the updates and the banded global alignments of region
 // patching spread across the lanes (sort_dedup_patch_wave / global_score_wave; rings in dynamic LDS).
 template <bool WAVE_PER_READ>
-__global__ void __launch_bounds__(64, 6) k_post1(DevIndex ix, MemOpt opt, TileView tv, int ring)
+__global__ void __launch_bounds__(64, WAVE_PER_READ ? 3 : 6) k_post1(DevIndex ix, MemOpt opt, TileView tv, int ring)
 {
     HIP_DYNAMIC_SHARED(int32_t, smem)
     const int r = WAVE_PER_READ ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);

@@ -84,6 +84,7 @@ struct SeqAcc {                  // query / target accessors with optional rever
 };
 DEV int acc_q(const SeqAcc& A, int j) { return A.q[A.rev ? A.qlen - 1 - j : j]; }
 DEV int acc_t(const DevIndex& ix, const SeqAcc& A, int i) { return ref_base2(ix, A.t0 + (A.rev ? A.tlen - 1 - i : i)); }
+#include "global_pk.h"
 
 // The same accessors for the per-base loops of the one-lane-per-read kernels, through a one-word cache each: 16
 // reference bases or 4 query bases per global load instead of one (those loops are bound by the latency of their
@@ -318,7 +319,21 @@ DEV bool gen_cigar2(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int w
         min_w = d + 3;
         w = w > min_w ? w : min_w;
         // a wavefront running this in lockstep aligns across its lanes when the band fits its rings (score only)
-        if (wd && !want_cigar && (2 * w + 4 <= wd->rm + 1 || l_query + 2 <= wd->rm + 1)) *score = global_score_wave(ix, opt, *wd, A, w);
+        bool done = false;
+        if (wd && !want_cigar) {                                   // the packed diagonal form first (global_pk.h): no rows in LDS, no barriers
+            const int nch = (2 * w + 1 + 63) >> 6, l_end = l_query - 1 - (rlen - 1 - w);
+            GpkFit fit;
+            if (l_end >= 0 && l_end <= 2 * w && nch <= 14 && gpk_fit(opt, w, (nch + 1) >> 1, fit)) {
+                int sc;
+                if (nch <= 2) sc = global_wave_diag_pk<1, false>(ix, opt, nullptr, wd->lane, A, w, fit, nullptr, false, 0, done);
+                else if (nch <= 4) sc = global_wave_diag_pk<2, false>(ix, opt, nullptr, wd->lane, A, w, fit, nullptr, false, 0, done);
+                else if (nch <= 8) sc = global_wave_diag_pk<4, false>(ix, opt, nullptr, wd->lane, A, w, fit, nullptr, false, 0, done);
+                else sc = global_wave_diag_pk<7, false>(ix, opt, nullptr, wd->lane, A, w, fit, nullptr, false, 0, done);
+                if (done) *score = sc;
+            }
+        }
+        if (done) { }
+        else if (wd && !want_cigar && (2 * w + 4 <= wd->rm + 1 || l_query + 2 <= wd->rm + 1)) *score = global_score_wave(ix, opt, *wd, A, w);
         else *score = global_dp(ix, opt, S, A, w, want_cigar, &n_cig);
     }
     if (want_cigar) {
