@@ -347,9 +347,9 @@ __global__ void __launch_bounds__(64, 2) k_gcigar_lane(DevIndex ix, MemOpt opt, 
 {
     constexpr int NS = 2 * WMAX + 1;                      // band slots
     constexpr int ZW = (NS + 7) / 8;                      // dwords of direction nibbles per row
-    const int job = blockIdx.x * 64 + threadIdx.x, lane = threadIdx.x;
-    const bool valid = job < n_jobs;
-    const DpJob jb = jobs[valid ? job : n_jobs - 1];
+    const int job = blockIdx.x * 64 + threadIdx.x;
+    if (job >= n_jobs) return;
+    const DpJob jb = jobs[job];
     const AlnReg ar = tv.regs[tv.seed_off[jb.read] + jb.reg];
     const uint8_t* query = tv.seq + tv.seq_off[jb.read];
     SeqAcc A; A.q = query + ar.qb; A.qlen = ar.qe - ar.qb; A.rev = ar.rb >= ix.l_pac; A.t0 = ar.rb; A.tlen = (int)(ar.re - ar.rb);
@@ -371,19 +371,13 @@ __global__ void __launch_bounds__(64, 2) k_gcigar_lane(DevIndex ix, MemOpt opt, 
     }
     const int l_end = qlen - 1 - (tlen - 1 - w);           // slot of the final cell
     uint32_t* z = 0;
-    bool take = valid && usable && w <= WMAX && l_end >= 0 && l_end <= 2 * w;
-    {   // the direction nibbles of the wavefront's jobs, lane-interleaved: word k of row i of lane l at ((i ZW + k) 64 + l), so that a
-        // row's stores are ZW coalesced 256-byte writes instead of 64 scattered ones each (one allocation per wavefront, sized by its
-        // longest job)
-        const int tl_max = wave_max(take ? tlen : 0);
-        const unsigned long long need = (unsigned long long)tl_max * ZW * 256ull;
-        unsigned long long at = 0;
-        if (tl_max > 0 && lane == 0) at = atomicAdd(zpool_cur, need);
-        at = (unsigned long long)__shfl((long long)at, 0);
-        if (tl_max > 0 && at + need > zpool_cap) { if (lane == 0) atomicOr(tv.err, ERR_ZPOOL); take = false; }
-        else z = (uint32_t*)(zpool + at) + lane;
+    bool take = usable && w <= WMAX && l_end >= 0 && l_end <= 2 * w;
+    if (take) {
+        const unsigned long long need = ((unsigned long long)tlen * ZW * 4 + 63ull) & ~63ull;
+        const unsigned long long at = atomicAdd(zpool_cur, need);
+        if (at + need > zpool_cap) { atomicOr(tv.err, ERR_ZPOOL); take = false; }
+        else z = (uint32_t*)(zpool + at);
     }
-    if (!valid) return;
     if (!take) { outs[job] = o; return; }
 
     const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
@@ -434,7 +428,7 @@ __global__ void __launch_bounds__(64, 2) k_gcigar_lane(DevIndex ix, MemOpt opt, 
         }
         E[NS - 1] = MINUS_INF;
 #pragma unroll
-        for (int k = 0; k < ZW; ++k) z[(i * ZW + k) * 64] = zw[k];
+        for (int k = 0; k < ZW; ++k) z[i * ZW + k] = zw[k];
         const int inj = i + 1 - w + NS - 1;                  // query position entering the last slot
         const int qin = inj >= 0 && inj < qlen ? acc_q_c(A, sc, inj) : 4;
 #pragma unroll
@@ -456,7 +450,7 @@ __global__ void __launch_bounds__(64, 2) k_gcigar_lane(DevIndex ix, MemOpt opt, 
         if (cur_len) { if (n >= cig_cap) ovf = true; else cigar[n++] = cur_len << 4 | (uint32_t)cur_op; } cur_op = (OP); cur_len = (uint32_t)(LEN); } } while (0)
     while (i >= 0 && k >= 0 && !ovf) {
         const int l = k - (i - w);
-        const uint32_t nib = z[(i * ZW + (l >> 3)) * 64] >> ((l & 7) << 2) & 15u;
+        const uint32_t nib = z[i * ZW + (l >> 3)] >> ((l & 7) << 2) & 15u;
         which = which == 0 ? (int)(nib & 3u) : which == 1 ? (int)(nib >> 2 & 1u) : (int)(nib >> 3 & 1u) << 1;
         if (which == 0) { TB_PUSH(0, 1); --i; --k; }
         else if (which == 1) { TB_PUSH(2, 1); --i; }
