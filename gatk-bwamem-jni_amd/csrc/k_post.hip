@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(64, WAVE_PER_READ ? 3 : 6) k_post1(DevIndex ix
     const int r = WAVE_PER_READ ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (r >= tv.n_reads) return;
     const bool writer = !WAVE_PER_READ || threadIdx.x == 0;
-    WaveDp wd; wd.eh_h = smem; wd.eh_e = smem + ring; wd.tmpM = smem + 2 * ring; wd.rm = ring - 1; wd.lane = (int)threadIdx.x;
+    WaveDp wd; wd.eh_h = smem; wd.eh_e = smem + ring; wd.tmpM = smem + 2 * ring; wd.rm = ring - 1; wd.lane = (int)threadIdx.x; wd.no_pk = (tv.debug & 0x10000) != 0;
     PostScratch S = post_scratch_for(tv, r);
     const uint8_t* query = tv.seq + tv.seq_off[r];
     AlnReg* a = tv.regs + tv.seed_off[r];

@@ -183,7 +183,7 @@ DEV int global_dp(const DevIndex& ix, const MemOpt& opt, PostScratch& S, const S
 // code in lockstep on the same read (k_post1_wave, long reads), where a lane-serial DP over thousands of rows would leave
 // 63 lanes idle.  Rows are rings in LDS around the band (cf. ExtLds in k_extend.hip); row i writes index i + w + 1 before
 // row i + 1 reads it, so only indices 0 .. w + 1 are initialised here.  Same recurrence and tie rules as global_dp.
-struct WaveDp { int32_t* eh_h; int32_t* eh_e; int32_t* tmpM; int rm; int lane; };
+struct WaveDp { int32_t* eh_h; int32_t* eh_e; int32_t* tmpM; int rm; int lane; bool no_pk; };   // no_pk: the rows-in-LDS form only (BWAMEM_HIP_DEBUGK bit 0x10000: tests)
 DEV int global_score_wave(const DevIndex& ix, const MemOpt& opt, const WaveDp& L, const SeqAcc& A, int w)
 {
     const int lane = L.lane, RM = L.rm;
@@ -320,7 +320,7 @@ DEV bool gen_cigar2(const DevIndex& ix, const MemOpt& opt, PostScratch& S, int w
         w = w > min_w ? w : min_w;
         // a wavefront running this in lockstep aligns across its lanes when the band fits its rings (score only)
         bool done = false;
-        if (wd && !want_cigar) {                                   // the packed diagonal form first (global_pk.h): no rows in LDS, no barriers
+        if (wd && !want_cigar && !wd->no_pk) {                     // the packed diagonal form first (global_pk.h): no rows in LDS, no barriers
             const int nch = (2 * w + 1 + 63) >> 6, l_end = l_query - 1 - (rlen - 1 - w);
             GpkFit fit;
             if (l_end >= 0 && l_end <= 2 * w && nch <= 14 && gpk_fit(opt, w, (nch + 1) >> 1, fit)) {

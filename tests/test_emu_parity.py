@@ -69,7 +69,7 @@ def test_emu_concurrent_tiles(emu, oracle, small_genome, monkeypatch):
     _cmp(emu, oracle, img, reads)
 
 
-def test_emu_long_reads_seed_rescoring(emu, oracle, small_genome):
+def test_emu_long_reads_seed_rescoring(emu, oracle, small_genome, monkeypatch):
     """reads long enough (5.5 ln L <= 0.05 L) to go through mem_flt_chained_seeds / mem_seed_sw (row a10)"""
     seqs, img = small_genome
     reads = B.simulate_reads(seqs, 2, length=800, seed=5, sub=0.06, indel=0.02)
@@ -81,6 +81,10 @@ def test_emu_long_reads_seed_rescoring(emu, oracle, small_genome):
     for p in range(50, len(rd), 173):
         rd[p] = ord("ACGT"[("ACGT".index(chr(rd[p])) + 1) % 4]) if chr(rd[p]) in "ACGT" else rd[p]
     _cmp(emu, oracle, img, [bytes(rd), B.revcomp(bytes(rd))])
+    # the same through the forms the packed 16-bit global alignments fall back to (32-bit diagonals in k_gcigar, rows in LDS behind
+    # mem_patch_reg): what a job takes whose values do not fit, or options whose penalties leave no room
+    monkeypatch.setenv("BWAMEM_HIP_DEBUGK", "65536")
+    _cmp(emu, oracle, img, [bytes(rd)])
 
 
 def test_emu_seed_work_queue_and_spill(emu, oracle, small_genome, monkeypatch):

@@ -329,13 +329,16 @@ def test_concurrent_calls_on_one_index(hip_lib, oracle, small_genome):
     assert got == want
 
 
-def test_parity_long_reads(hip_lib, oracle, medium_genome):
+def test_parity_long_reads(hip_lib, oracle, medium_genome, monkeypatch):
     """config-5 style reads: seed re-scoring (row a10), wide bands, long chains, big global alignments"""
     seqs, img = medium_genome
     reads = B.simulate_reads(seqs, 150, length=1000, seed=5, sub=0.06, indel=0.02, random_frac=0.0)
     reads += B.simulate_reads(seqs, 40, length=3000, seed=6, sub=0.08, indel=0.03, random_frac=0.0)
     reads += B.simulate_reads(seqs, 6, length=10000, seed=7, sub=0.08, indel=0.06, random_frac=0.0)
-    _parity(hip_lib, oracle, img, reads)
+    got = _parity(hip_lib, oracle, img, reads)
+    # the forms the packed 16-bit global alignments fall back to (32-bit diagonals in k_gcigar, rows in LDS behind mem_patch_reg)
+    monkeypatch.setenv("BWAMEM_HIP_DEBUGK", "65536")
+    assert _parity(hip_lib, oracle, img, reads) == got
 
 
 def test_parity_reads_beyond_lds_rows(hip_lib, oracle, medium_genome, small_genome, monkeypatch):
