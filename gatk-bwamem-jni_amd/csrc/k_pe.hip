@@ -306,13 +306,26 @@ DEV bool pe_heavy(const MemOpt& opt, int debug, int n0, int n1) { return n0 + n1
 
 // mate rescue, step 1 (one lane per pair): list the alignments the rescue of this pair may ask for
 __global__ void k_pe_rescue_plan(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3,
-                                 RescueJob* jobs, int32_t* job_first, int32_t* job_num, int32_t* counter, int cap)
+                                 RescueJob* jobs, int32_t* job_first, int32_t* job_num, int32_t* counter, int cap, int32_t* heavy_list, int32_t* heavy_cnt)
 {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pi >= tv.n_reads >> 1) return;
+    const bool valid = pi < tv.n_reads >> 1;
     const MemPestat pes[4] = { p0, p1, p2, p3 };
-    PeCtx c = pe_ctx(tv, pv, pi);
-    if (pe_heavy(opt, tv.debug, c.n[0], c.n[1])) return;       // k_pe_rescue_plan_wave's
+    PeCtx c = pe_ctx(tv, pv, valid ? pi : 0);
+    {   // the heavy pairs are the wavefront kernels': listed here (one atomic per wavefront), so that those kernels are launched
+        // over the list and not over every pair (an empty workgroup of theirs costs ~8 ns: 2.4 % of a paired-end step on a genome
+        // that has no heavy pair at all)
+        const bool heavy = valid && pe_heavy(opt, tv.debug, c.n[0], c.n[1]);
+        const unsigned long long hm = __ballot(heavy);
+        if (hm) {
+            const int l_ = threadIdx.x & 63, src = __ffsll((long long)hm) - 1;
+            int base = 0;
+            if (l_ == src) base = atomicAdd(heavy_cnt, __popcll(hm));
+            base = __shfl(base, src);
+            if (heavy) heavy_list[base + __popcll(hm & ((1ull << l_) - 1ull))] = pi;
+        }
+        if (!valid || heavy) return;
+    }
     PeScratch P = pe_scratch(opt, pv, pi);
     const long long t0 = (tv.debug & 0x2000) ? clock64() : 0;
     int n_anch[2];
@@ -365,12 +378,15 @@ DEV int rescue_skip_wave(const DevIndex& ix, const MemPestat* pes, const AlnReg&
 
 // mate rescue, step 1 for a heavy pair: one wavefront (workgroup) per pair; light pairs return at once
 __global__ void __launch_bounds__(64) k_pe_rescue_plan_wave(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3,
-                                                            RescueJob* jobs, int32_t* job_first, int32_t* job_num, int32_t* counter, int cap)
+                                                            RescueJob* jobs, int32_t* job_first, int32_t* job_num, int32_t* counter, int cap, const int32_t* heavy_list, const int32_t* heavy_cnt)
 {
     __shared__ uint8_t skip_s[2 * PE_WAVE_MAX_ANCHORS];
-    const int pi = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
+    const int n_heavy = *heavy_cnt;
+  for (int hi = blockIdx.x; hi < n_heavy; hi += (int)gridDim.x) {       // (a bounded grid walks the list of heavy pairs)
+    const int pi = heavy_list[hi];
+    __syncthreads();                                                    // the previous pair is done with skip_s
     PeCtx c = pe_ctx(tv, pv, pi);
-    if (!pe_heavy(opt, tv.debug, c.n[0], c.n[1])) return;
     const MemPestat pes[4] = { p0, p1, p2, p3 };
     PeScratch P = pe_scratch(opt, pv, pi);
     int n_anch[2] = { 0, 0 };
@@ -414,6 +430,7 @@ __global__ void __launch_bounds__(64) k_pe_rescue_plan_wave(DevIndex ix, MemOpt 
         }
     }
     if (lane == 0) { job_first[pi] = first; job_num[pi] = cnt; }
+  }
 }
 
 // mate rescue, step 2: ksw_align2 for the listed alignments, four per wavefront (one per 16-lane group, sw_common.h).
@@ -543,12 +560,15 @@ DEV void matesw_wave(const DevIndex& ix, const MemOpt& opt, SwScratch& W, const 
 // mate rescue, step 3 for the heavy pairs: one wavefront per pair replays upstream's sequence on both ends' lists and leaves
 // the new region counts; k_pe_pair then finds job_num < 0 and goes straight on to primary marking
 __global__ void __launch_bounds__(64) k_pe_matesw_wave(DevIndex ix, MemOpt opt, TileView tv, PeView pv, MemPestat p0, MemPestat p1, MemPestat p2, MemPestat p3,
-                                                       const RescueJob* rjobs, const KswR* rres, const int32_t* job_first, int32_t* job_num)
+                                                       const RescueJob* rjobs, const KswR* rres, const int32_t* job_first, int32_t* job_num, const int32_t* heavy_list, const int32_t* heavy_cnt)
 {
-    const int pi = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     if (tv.err[0] & ERR_RESCUE_CAP) return;
+    const int n_heavy = *heavy_cnt;
+  for (int hi = blockIdx.x; hi < n_heavy; hi += (int)gridDim.x) {
+    const int pi = heavy_list[hi];
+    __syncthreads();
     PeCtx c = pe_ctx(tv, pv, pi);
-    if (!pe_heavy(opt, tv.debug, c.n[0], c.n[1])) return;
     const MemPestat pes[4] = { p0, p1, p2, p3 };
     PeScratch P = pe_scratch(opt, pv, pi);
     SortKey* const kbase = pv.keys && !(tv.debug & 0x400) ? (SortKey*)pv.keys : nullptr;
@@ -568,6 +588,7 @@ __global__ void __launch_bounds__(64) k_pe_matesw_wave(DevIndex ix, MemOpt opt, 
         job_num[pi] = -1;
         if (err) atomicOr(tv.err, err);
     }
+  }
 }
 
 // mem_sam_pe, first half (one lane per pair): mate rescue (step 3: upstream's sequence with the alignments precomputed),
@@ -860,15 +881,18 @@ void launch_pe_pair(hipStream_t st, const DevIndex& ix, const MemOpt& opt, const
     if (np <= 0) return;
     PeView pv; pv.regs = regs; pv.reg_off = reg_off; pv.n_regs = n_regs; pv.ints = ints; pv.vpool = vpool; pv.keys = keys; pv.scratch = scratch;
     pv.scratch_per_pair = scratch_per_pair; pv.cap_h = cap_h; pv.cap_b = cap_b; pv.cap_u = cap_u; pv.ptab = ptab;
-    (void)hipMemsetAsync(rescue_cnt, 0, 4, st);
+    (void)hipMemsetAsync(rescue_cnt, 0, 8, st);                      // [0] rescue jobs, [1] heavy pairs
+    int32_t* const heavy_list = rescue_num + (np + 1);               // behind the per-pair arrays (pipeline.cpp sizes the buffer)
+    int32_t* const heavy_cnt = rescue_cnt + 1;
+    const int wave_grid = np < 8192 ? np : 8192;
     if (!(opt.flag & MEM_F_NO_RESCUE)) {
         hipLaunchKernelGGL(k_pe_rescue_plan, dim3((np + 127) / 128), dim3(128), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3],
-                           (RescueJob*)rescue_jobs, rescue_first, rescue_num, rescue_cnt, rescue_cap);
-        hipLaunchKernelGGL(k_pe_rescue_plan_wave, dim3(np), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3],
-                           (RescueJob*)rescue_jobs, rescue_first, rescue_num, rescue_cnt, rescue_cap);
+                           (RescueJob*)rescue_jobs, rescue_first, rescue_num, rescue_cnt, rescue_cap, heavy_list, heavy_cnt);
+        hipLaunchKernelGGL(k_pe_rescue_plan_wave, dim3(wave_grid), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3],
+                           (RescueJob*)rescue_jobs, rescue_first, rescue_num, rescue_cnt, rescue_cap, heavy_list, heavy_cnt);
         launch_sw_jobs(st, ix, opt, tv, rescue_jobs, rescue_cnt, rescue_cap, rescue_res, cap_b, tv.max_len);
-        hipLaunchKernelGGL(k_pe_matesw_wave, dim3(np), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3],
-                           (const RescueJob*)rescue_jobs, (const KswR*)rescue_res, (const int32_t*)rescue_first, rescue_num);
+        hipLaunchKernelGGL(k_pe_matesw_wave, dim3(wave_grid), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3],
+                           (const RescueJob*)rescue_jobs, (const KswR*)rescue_res, (const int32_t*)rescue_first, rescue_num, heavy_list, heavy_cnt);
     }
     hipLaunchKernelGGL(k_pe_pair, dim3((np + 63) / 64), dim3(64), 0, st, ix, opt, tv, pv, pes[0], pes[1], pes[2], pes[3], (PeState*)states,
                        (const RescueJob*)rescue_jobs, (const KswR*)rescue_res, (const int32_t*)rescue_first, (const int32_t*)rescue_num);

@@ -1224,7 +1224,7 @@ static bool pe_phase2_tile(bwaidx_s* ix, Workspace& ws, const MemOpt& opt, bwame
         {   // rescue alignments: a few per cent of the pairs ask for one, pairs in repeats for many
             static const int floor0 = []{ const char* e = getenv("BWAMEM_HIP_PE_RESCUE_CAP0"); return e && atoi(e) > 0 ? atoi(e) : 4096; }();   // test knob: start small, take the resize path
             const int rc = std::max(pe_rescue_cap, floor0 < 4096 ? floor0 : std::max(4096, T / 8));
-            PE_REQ(ws.pe_rescue[0].ensure(pe_rescue_bytes(0, rc)) && ws.pe_rescue[1].ensure(pe_rescue_bytes(1, rc)) && ws.pe_rescue[2].ensure((size_t)(T / 2 + 1) * 8 + 64));
+            PE_REQ(ws.pe_rescue[0].ensure(pe_rescue_bytes(0, rc)) && ws.pe_rescue[1].ensure(pe_rescue_bytes(1, rc)) && ws.pe_rescue[2].ensure((size_t)(T / 2 + 1) * 12 + 64));   // header, first / count of each pair's rescue jobs, list of the heavy pairs
             pe_rescue_cap = rc;
         }
         TIMED(ws, K_FINAL, launch_pe_pair(ws.stream, ix->d, opt, tv, regs2, reg_off2, tv.n_regs, ws.pe_ints2.as<int32_t>(), ws.pe_vpool.p, (char*)ws.pe_vpool.p + (((size_t)(tot + 2) * 16 + 63) & ~(size_t)63),
